@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def load_case(name):
+    """A golden case: the edge list fed to the reference + the reference's outputs (tests/golden/make_golden.py)."""
+    z = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if "edges" not in z:  # the reference's own bundled samples are kept as the original files
+        z["edges"] = np.fromfile(os.path.join(GOLDEN, "rmat10_1024.bin"), dtype="<u4").reshape(-1, 2)
+        z["wedges"] = np.fromfile(os.path.join(GOLDEN, "rmat10_1024_w.bin"), dtype="<u4").reshape(-1, 3)
+    z["num_vertices"] = int(z["num_vertices"]); z["root"] = int(z["root"])
+    return z
+
+
+CASES = ["tiny", "rmat8", "rmat10", "rmat12"]
+FIRST_NP = {"tiny": 1, "rmat8": 1, "rmat10": 1, "rmat12": 1}
+OTHER_NP = {"tiny": 2, "rmat8": 2, "rmat10": 4, "rmat12": 8}
+
+
+@pytest.fixture(scope="session")
+def known_answers():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "known_answers.json")))
