@@ -1,0 +1,112 @@
+"""ctypes binding of include/graphtap_amd.h. There is NO CPU fallback: a missing library or a
+missing GPU raises, it never degrades to another implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgraphtap_amd.so")
+
+GT_INF = 2147483647
+GT_DEG, GT_PR, GT_BFS, GT_SSSP, GT_CC = range(5)
+GT_ROW, GT_COL = 0, 1
+GT_TCSC, GT_TCSC_CF = 0, 1
+GT_PLUS_F64, GT_PLUS_U32, GT_MIN_U32, GT_MINPLUS_U32 = range(4)
+GT_F_DEGREE, GT_F_RANK, GT_F_PARENT, GT_F_HOPS, GT_F_DISTANCE, GT_F_LABEL, GT_F_ACTIVE = range(7)
+
+
+class GraphTapError(RuntimeError):
+    pass
+
+
+class GraphFlags(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("directed", "transpose", "self_loops", "acyclic", "parallel_edges")]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint32), ("nrows", C.c_uint32), ("tile_height", C.c_uint32),
+                ("rank", C.c_uint32), ("nranks", C.c_uint32), ("nnzrows", C.c_uint32), ("nnzcols", C.c_uint32),
+                ("seg_stride", C.c_uint32), ("nnz_local", C.c_uint64), ("nnz_global", C.c_uint64),
+                ("nnzrows_global", C.c_uint64), ("nnzcols_global", C.c_uint64), ("weighted", C.c_int32),
+                ("regular", C.c_uint32), ("source_rows", C.c_uint32), ("sink_cols", C.c_uint32)]
+
+
+class TileArrays(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("JA", "IA", "A", "JC", "IR")]
+
+
+class ProgramParams(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("order", C.c_int32), ("compression", C.c_int32), ("root", C.c_uint32),
+                ("alpha", C.c_double), ("tol", C.c_double)]
+
+
+class ExecStats(C.Structure):
+    _fields_ = [("iterations", C.c_uint32), ("converged", C.c_uint32), ("seconds", C.c_double),
+                ("spmv_ms", C.c_double), ("spmv_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/graphtap_amd.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "gt_abi_version": (C.c_int, []),
+    "gt_last_error": (C.c_char_p, []),
+    "gt_device_count": (C.c_int, []),
+    "gt_set_device": (C.c_int, [C.c_int]),
+    "gt_graph_build": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int]),
+    "gt_graph_info_get": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
+    "gt_graph_tile": (C.c_int, [_vp, C.POINTER(TileArrays)]),
+    "gt_graph_free": (C.c_int, [_vp]),
+    "gt_program_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(ProgramParams)]),
+    "gt_program_initialize": (C.c_int, [_vp]),
+    "gt_program_initialize_from": (C.c_int, [_vp, _vp]),
+    "gt_program_execute": (C.c_int, [_vp, C.c_uint32, C.POINTER(ExecStats)]),
+    "gt_program_set_stream": (C.c_int, [_vp, _vp]),
+    "gt_program_x": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "gt_program_set_x": (C.c_int, [_vp, _vp]),
+    "gt_program_scatter_gather": (C.c_int, [_vp]),
+    "gt_program_combine": (C.c_int, [_vp]),
+    "gt_program_apply": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "gt_program_finish_converged": (C.c_int, [_vp]),
+    "gt_program_iteration": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "gt_program_y": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "gt_program_copy_state": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
+    "gt_program_checksum": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gt_program_free": (C.c_int, [_vp]),
+    "gt_spmv": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "gt_rmat_generate": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, _vp]),
+    "gt_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "gt_free": (C.c_int, [_vp]),
+    "gt_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "gt_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "gt_memset": (C.c_int, [_vp, C.c_int, C.c_uint64]),
+    "gt_device_synchronize": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises GraphTapError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GraphTapError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(graphtap_amd has no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        if L.gt_abi_version() != 1:
+            raise GraphTapError("ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise GraphTapError("graphtap_amd error %d: %s" % (status, lib().gt_last_error().decode()))
+
+
+def require_gpu():
+    if lib().gt_device_count() <= 0:
+        raise GraphTapError("no HIP device visible: graphtap_amd has no CPU fallback")

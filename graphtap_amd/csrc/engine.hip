@@ -1,0 +1,592 @@
+// engine.hip -- vertex-program engine + the extern "C" ABI of include/graphtap_amd.h.
+//
+// Replaces Vertex_Program<> (src/vp/vertex_program.hpp): state vectors V / C live in HBM as
+// struct-of-arrays over the owned vertex segment; messenger (K7/K8), applicator (K10/K11) and
+// the convergence count (K12) are kernels; the five apps' hooks (src/apps/*.h) are op-codes.
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "gt_internal.h"
+
+// ------------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void gt_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+constexpr int TPB = 256;
+inline unsigned grid_for(uint64_t n) {
+    uint64_t b = (n + TPB - 1) / TPB;
+    if (b < 1) b = 1;
+    if (b > 256u * 16u) b = 256u * 16u;
+    return (unsigned)b;
+}
+}  // namespace
+
+struct gt_program {
+    gt_graph *g = nullptr;
+    gt_program_params prm{};
+    bool stationary = true;
+    bool initialized = false;
+    bool converged = false;
+    uint32_t iteration = 0;
+    int semiring = 0;
+    hipStream_t stream = 0;
+    // V (vp:61) as struct-of-arrays over the owned segment, H entries each
+    uint32_t *s0 = nullptr;  // degree | parent | distance | label
+    uint32_t *s1 = nullptr;  // hops (BFS)
+    double *rank = nullptr;  // PageRank
+    uint8_t *C = nullptr;    // vp:161
+    // messages / accumulators (vp:159-160)
+    void *x_own = nullptr, *x = nullptr, *y = nullptr;
+    uint64_t x_elems = 0, y_elems = 0;
+    uint32_t x_bytes = 4, y_bytes = 4;
+    unsigned long long *d_active = nullptr;
+    std::vector<hipEvent_t> ev;  // SpMV timing pairs
+    size_t ev_used = 0;
+};
+
+// ------------------------------------------------------------------ messenger kernels (K7/K8)
+// scatter_gather_stationary vp:688-708 / _nonstationary vp:711-758 over the owned segment's
+// non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs.
+__global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[j] = 1u;  // deg.h:35-37
+}
+__global__ void k_msg_pr(double *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
+                         const uint32_t *__restrict__ deg, const double *__restrict__ rank) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
+        uint32_t v = JC[j], d = deg[v];
+        x[j] = d ? rank[v] / (double)d : 0.0;  // pr.h:31-33
+    }
+}
+__global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
+                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, int kind) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
+        uint32_t v = JC[j];
+        // bfs.h:52-54 (vid), sssp.h:44-46 (distance), cc.h:38-40 (label); inactive -> infinity() vp:749-750
+        x[j] = C[v] ? (kind == GT_BFS ? vid_base + v : s0[v]) : GT_INF;
+    }
+}
+
+// Deg in _COL_ order (apps/pr.cpp:40-42; vp:1174-1184 with x == 1): y[c] = entries in column c
+__global__ void k_col_counts(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t *__restrict__ y) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) y[c] = JA[c + 1] - JA[c];
+}
+
+// ------------------------------------------------------------------ applicator kernels (K10/K11)
+__device__ __forceinline__ void count_active(unsigned act, unsigned long long *d_active) {
+    for (int o = 32; o > 0; o >>= 1) act += __shfl_down(act, o);
+    if ((threadIdx.x & 63) == 0 && act) atomicAdd(d_active, (unsigned long long)act);
+}
+
+// rows without an accumulator slot: C[i] = applicator(state) = false (vp:1666-1667, 1735-1736)
+__global__ void k_clear_empty_rows(uint8_t *__restrict__ C, const uint8_t *__restrict__ IJ, uint32_t H) {
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < H; v += gridDim.x * blockDim.x)
+        if (!(IJ[v] & 1)) C[v] = 0;
+}
+
+__global__ void k_apply_deg_row(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
+                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        uint32_t v = IR[r];
+        deg[v] = y[r]; C[v] = 0;  // deg.h:47-50
+    }
+}
+__global__ void k_apply_deg_col(const uint32_t *__restrict__ y_seg, const uint32_t *__restrict__ JC, uint32_t nc,
+                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
+        uint32_t v = JC[j];
+        deg[v] = y_seg[j]; C[v] = 0;
+    }
+}
+// pr.h:43-47. cf: TCSC_CF touches regular rows every iteration and source rows (no column,
+// R2C == ~0) on the last one (vp:1671-1691); only regular rows count towards convergence (vp:1902-1916).
+__global__ void k_apply_pr(const double *__restrict__ y, const uint32_t *__restrict__ IR, const uint32_t *__restrict__ R2C,
+                           uint32_t nr, double *__restrict__ rank, uint8_t *__restrict__ C, double alpha, double tol,
+                           int cf, int last, unsigned long long *d_active) {
+    unsigned act = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        bool source = (R2C[r] == 0xFFFFFFFFu);
+        if (cf && source && !last) continue;
+        uint32_t v = IR[r];
+        double tmp = rank[v];
+        double nv = alpha + (1.0 - alpha) * y[r];
+        rank[v] = nv;
+        uint8_t c = fabs(nv - tmp) > tol;
+        C[v] = c;
+        act += (c && !(cf && source));
+    }
+    count_active(act, d_active);
+}
+__global__ void k_apply_bfs(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
+                            uint32_t *__restrict__ parent, uint32_t *__restrict__ hops, uint8_t *__restrict__ C,
+                            uint32_t iteration, unsigned long long *d_active) {
+    unsigned act = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        uint32_t v = IR[r], yv = y[r];
+        uint8_t c = 0;  // bfs.h:65-77
+        if (hops[v] == GT_INF && yv != GT_INF) { hops[v] = iteration + 1; parent[v] = yv; c = 1; }
+        C[v] = c; act += c;
+    }
+    count_active(act, d_active);
+}
+__global__ void k_apply_min(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
+                            uint32_t *__restrict__ s0, uint8_t *__restrict__ C, unsigned long long *d_active) {
+    unsigned act = 0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        uint32_t v = IR[r], yv = y[r], tmp = s0[v];  // sssp.h:57-65 (HAS_WEIGHT), cc.h:51-55
+        uint32_t nv = yv < tmp ? yv : tmp;
+        s0[v] = nv;
+        uint8_t c = (nv != tmp);
+        C[v] = c; act += c;
+    }
+    count_active(act, d_active);
+}
+// the TCSC_CF converged tail (vp:425-428 -> 1683-1691): source rows get alpha + (1-alpha) * 0
+__global__ void k_pr_cf_tail(const uint32_t *__restrict__ IR, const uint32_t *__restrict__ R2C, uint32_t nr,
+                             double *__restrict__ rank, double alpha) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x)
+        if (R2C[r] == 0xFFFFFFFFu) rank[IR[r]] = alpha + (1.0 - alpha) * 0.0;
+}
+
+// ------------------------------------------------------------------ init kernels
+template <class T> __global__ void k_fill(T *__restrict__ p, uint64_t n, T v) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// initializer(vid, state): bfs.h:37-50, sssp.h:33-42, cc.h:33-36
+__global__ void k_init_min(int kind, uint32_t H, uint32_t vid_base, uint32_t root, uint32_t *__restrict__ s0,
+                           uint32_t *__restrict__ s1, uint8_t *__restrict__ C) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) {
+        uint32_t vid = vid_base + i;
+        if (kind == GT_BFS) { s0[i] = (vid == root) ? vid : 0; s1[i] = (vid == root) ? 0 : GT_INF; C[i] = (vid == root); }
+        else if (kind == GT_SSSP) { s0[i] = (vid == root) ? 0 : GT_INF; C[i] = (vid == root); }
+        else { s0[i] = vid; C[i] = 1; }
+    }
+}
+// initialize(other), vp:476-483 with pr.h:24-28: degree copied only where the row is non-empty
+__global__ void k_pr_take_degree(uint32_t H, const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ other_deg,
+                                 uint32_t *__restrict__ deg) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x)
+        deg[i] = (IJ[i] & 1) ? other_deg[i] : 0;
+}
+
+// ------------------------------------------------------------------ R-MAT generator
+// counter based; bit-identical to graphtap_amd/rmat.py (SURVEY 8d parameters)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_rmat(uint32_t *__restrict__ out, int scale, uint64_t seed, int weighted, uint64_t first, uint64_t count) {
+    const uint64_t GOLDEN = 0x9E3779B97F4A7C15ull;
+    const int stride = weighted ? 3 : 2;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t base = mix64(seed * GOLDEN + (first + i));
+        uint32_t src = 0, dst = 0;
+        for (int l = 0; l < scale; l++) {
+            uint32_t u = (uint32_t)(mix64(base + (uint64_t)(l + 1) * GOLDEN) >> 32);
+            uint32_t rbit = (u >= 3264175144u);
+            uint32_t cbit = ((u >= 2448131358u) & (u < 3264175144u)) | (u >= 4080218931u);
+            src = (src << 1) | rbit; dst = (dst << 1) | cbit;
+        }
+        out[i * stride] = src; out[i * stride + 1] = dst;
+        if (weighted) out[i * stride + 2] = (uint32_t)(mix64(base ^ 0xD1B54A32D192ED03ull) % 128ull) + 1u;
+    }
+}
+
+// =============================================================================== C ABI
+extern "C" {
+
+int gt_abi_version(void) { return GT_ABI_VERSION; }
+const char *gt_last_error(void) { return g_err; }
+
+int gt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int gt_set_device(int device) {
+    GT_REQUIRE(gt_device_count() > 0, GT_ERR_NO_DEVICE, "no HIP device visible: graphtap_amd has no CPU fallback");
+    GT_HIP(hipSetDevice(device));
+    return GT_OK;
+}
+
+int gt_malloc(void **p, uint64_t bytes) { GT_HIP(hipMalloc(p, bytes ? bytes : 1)); return GT_OK; }
+int gt_free(void *p) { GT_HIP(hipFree(p)); return GT_OK; }
+int gt_memcpy_h2d(void *d, const void *h, uint64_t bytes) { GT_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return GT_OK; }
+int gt_memcpy_d2h(void *h, const void *d, uint64_t bytes) { GT_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return GT_OK; }
+int gt_memset(void *d, int v, uint64_t bytes) { GT_HIP(hipMemset(d, v, bytes)); return GT_OK; }
+int gt_device_synchronize(void) { GT_HIP(hipDeviceSynchronize()); return GT_OK; }
+
+int gt_rmat_generate(void *dev_out, int scale, uint64_t seed, int weighted, uint64_t first, uint64_t count, void *hip_stream) {
+    GT_REQUIRE(dev_out && scale > 0 && scale <= 31, GT_ERR_INVALID, "gt_rmat_generate: bad arguments");
+    if (count) k_rmat<<<grid_for(count), TPB, 0, (hipStream_t)hip_stream>>>((uint32_t *)dev_out, scale, seed, weighted, first, count);
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+
+// ---- graph
+int gt_graph_free(gt_graph *g) {
+    if (!g) return GT_OK;
+    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete g;
+    return GT_OK;
+}
+
+int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                   uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks) {
+    GT_REQUIRE(out && flags && (edges || m == 0), GT_ERR_INVALID, "gt_graph_build: null argument");
+    GT_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, GT_ERR_INVALID, "gt_graph_build: rank %d of %d", rank, nranks);
+    GT_REQUIRE(num_vertices < 0xFFFFFFF0u - (uint32_t)nranks, GT_ERR_INVALID, "num_vertices too large for 32-bit vertex ids");
+    GT_REQUIRE(gt_device_count() > 0, GT_ERR_NO_DEVICE, "no HIP device visible: graphtap_amd has no CPU fallback");
+    *out = nullptr;
+    gt_graph *g = new gt_graph();
+    g->flags = *flags;
+    g->info.num_vertices = num_vertices;
+    g->info.nrows = num_vertices + 1;                          // mat/graph.hpp:89-90
+    g->info.nranks = (uint32_t)nranks; g->info.rank = (uint32_t)rank;
+    g->info.tile_height = g->info.nrows / (uint32_t)nranks + 1;  // mat/matrix.hpp:193
+    g->info.weighted = weighted ? 1 : 0;
+    const void *dev_edges = edges;
+    void *staged = nullptr;
+    const uint64_t bytes = m * (weighted ? 12ull : 8ull);
+    if (!edges_on_device && m) {
+        if (hipMalloc(&staged, bytes) != hipSuccess) { delete g; gt_set_error("out of device memory staging %llu edge bytes", (unsigned long long)bytes); return GT_ERR_HIP; }
+        if (hipMemcpy(staged, edges, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(staged); delete g; gt_set_error("H2D copy of the edge list failed"); return GT_ERR_HIP; }
+        dev_edges = staged;
+    }
+    int st = gt_ingest(g, dev_edges, m, weighted);
+    if (staged) (void)hipFree(staged);
+    if (st != GT_OK) { gt_graph_free(g); return st; }
+    *out = g;
+    return GT_OK;
+}
+
+int gt_graph_info_get(const gt_graph *g, gt_graph_info *info) {
+    GT_REQUIRE(g && info, GT_ERR_INVALID, "null argument");
+    *info = g->info;
+    return GT_OK;
+}
+int gt_graph_tile(const gt_graph *g, gt_tile_arrays *a) {
+    GT_REQUIRE(g && a, GT_ERR_INVALID, "null argument");
+    a->JA = g->JA; a->IA = g->IA; a->A = g->A; a->JC = g->JC; a->IR = g->IR;
+    return GT_OK;
+}
+
+int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream) {
+    GT_REQUIRE(g && x_dev && y_dev, GT_ERR_INVALID, "null argument");
+    return gt_launch_spmv(g, semiring, x_dev, y_dev, (hipStream_t)hip_stream);
+}
+
+// ---- programs
+int gt_program_free(gt_program *p) {
+    if (!p) return GT_OK;
+    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    return GT_OK;
+}
+
+int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *prm) {
+    GT_REQUIRE(out && g && prm, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(prm->kind >= GT_DEG && prm->kind <= GT_CC, GT_ERR_INVALID, "unknown program kind %d", prm->kind);
+    GT_REQUIRE(prm->order == GT_ROW || (prm->order == GT_COL && prm->kind == GT_DEG), GT_ERR_UNSUPPORTED,
+               "_COL_ ordering is implemented for the Degree program only (the reference says the same for TCSC_CF, vp:1319-1322)");
+    GT_REQUIRE(prm->kind != GT_SSSP || g->info.weighted, GT_ERR_INVALID,
+               "SSSP needs a weighted graph (12-byte records; the reference builds sssp with -DHAS_WEIGHT)");
+    *out = nullptr;
+    gt_program *p = new gt_program();
+    p->g = g; p->prm = *prm;
+    p->stationary = (prm->kind == GT_DEG || prm->kind == GT_PR);  // apps/*.cpp
+    switch (prm->kind) {
+        case GT_DEG: p->semiring = GT_PLUS_U32; break;
+        case GT_PR: p->semiring = GT_PLUS_F64; p->x_bytes = p->y_bytes = 8; break;
+        case GT_SSSP: p->semiring = GT_MINPLUS_U32; break;
+        default: p->semiring = GT_MIN_U32; break;
+    }
+    const uint32_t H = g->info.tile_height;
+    p->x_elems = g->ncols_total;
+    p->y_elems = (prm->order == GT_COL) ? g->ncols_total : g->info.nnzrows;
+    bool ok = hipMalloc((void **)&p->s0, (uint64_t)H * 4) == hipSuccess && hipMalloc((void **)&p->C, H) == hipSuccess &&
+              hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_bytes) == hipSuccess &&
+              hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
+              hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
+    if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
+    if (ok && prm->kind == GT_PR) ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess;
+    if (!ok) { gt_program_free(p); gt_set_error("out of device memory for program state"); return GT_ERR_HIP; }
+    p->x = p->x_own;
+    *out = p;
+    return GT_OK;
+}
+
+int gt_program_set_stream(gt_program *p, void *hip_stream) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    p->stream = (hipStream_t)hip_stream;
+    return GT_OK;
+}
+
+static int init_common(gt_program *p) {
+    const gt_graph *g = p->g;
+    const uint32_t H = g->info.tile_height, base = g->info.rank * H;
+    hipStream_t s = p->stream;
+    p->iteration = 0; p->converged = false;
+    switch (p->prm.kind) {
+        case GT_DEG:  // deg.h:31-34
+            GT_HIP(hipMemsetAsync(p->s0, 0, (uint64_t)H * 4, s));
+            GT_HIP(hipMemsetAsync(p->C, 1, H, s));
+            break;
+        case GT_PR:   // PR_State default rank = alpha (pr.h:15-16); base initializer returns `stationary`
+            GT_HIP(hipMemsetAsync(p->s0, 0, (uint64_t)H * 4, s));
+            k_fill<double><<<grid_for(H), TPB, 0, s>>>(p->rank, H, p->prm.alpha);
+            GT_HIP(hipMemsetAsync(p->C, 1, H, s));
+            break;
+        default:
+            k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, p->prm.root, p->s0, p->s1, p->C);
+            break;
+    }
+    // messages: padding columns are never referenced; give them the semiring's neutral message
+    if (p->x_bytes == 8) k_fill<double><<<grid_for(p->x_elems), TPB, 0, s>>>((double *)p->x, p->x_elems, 0.0);
+    else k_fill<uint32_t><<<grid_for(p->x_elems), TPB, 0, s>>>((uint32_t *)p->x, p->x_elems, p->stationary ? 0u : GT_INF);
+    // accumulators: init_nonstationary fills y with infinity() (vp:625-635); stationary y is zeroed per combine
+    if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
+    GT_HIP(hipGetLastError());
+    p->initialized = true;
+    return GT_OK;
+}
+
+int gt_program_initialize(gt_program *p) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    return init_common(p);
+}
+
+int gt_program_initialize_from(gt_program *p, const gt_program *other) {
+    GT_REQUIRE(p && other, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(p->g->info.tile_height == other->g->info.tile_height && p->g->info.rank == other->g->info.rank, GT_ERR_INVALID,
+               "initialize(other): the two programs cover different vertex segments");
+    int st = init_common(p);
+    if (st != GT_OK) return st;
+    if (p->prm.kind == GT_PR) {
+        GT_REQUIRE(other->prm.kind == GT_DEG || other->prm.kind == GT_PR, GT_ERR_INVALID, "PageRank initializes from a Degree program (apps/pr.cpp:47-48)");
+        const uint32_t H = p->g->info.tile_height;
+        k_pr_take_degree<<<grid_for(H), TPB, 0, p->stream>>>(H, p->g->IJ, other->s0, p->s0);
+        GT_HIP(hipGetLastError());
+    }
+    // non-stationary programs ignore `other` (vp:489-493)
+    return GT_OK;
+}
+
+int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    if (dev_ptr) *dev_ptr = p->x;
+    if (elems) *elems = p->x_elems;
+    if (elem_bytes) *elem_bytes = p->x_bytes;
+    return GT_OK;
+}
+int gt_program_set_x(gt_program *p, void *dev_ptr) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    p->x = dev_ptr ? dev_ptr : p->x_own;
+    return GT_OK;
+}
+int gt_program_y(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    if (dev_ptr) *dev_ptr = p->y;
+    if (elems) *elems = p->y_elems;
+    if (elem_bytes) *elem_bytes = p->y_bytes;
+    return GT_OK;
+}
+int gt_program_iteration(const gt_program *p, uint32_t *iteration) {
+    GT_REQUIRE(p && iteration, GT_ERR_INVALID, "null argument");
+    *iteration = p->iteration;
+    return GT_OK;
+}
+
+int gt_program_scatter_gather(gt_program *p) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "scatter_gather before initialize");
+    const gt_graph *g = p->g;
+    const uint32_t nc = g->info.nnzcols;
+    if (p->prm.order == GT_COL || nc == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
+    const uint64_t off = (uint64_t)g->info.rank * g->info.seg_stride;
+    hipStream_t s = p->stream;
+    switch (p->prm.kind) {
+        case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, nc); break;
+        case GT_PR: k_msg_pr<<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank); break;
+        default:
+            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, g->JC, nc, p->C, p->s0,
+                                                   g->info.rank * g->info.tile_height, p->prm.kind);
+            break;
+    }
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+
+static int combine_impl(gt_program *p, bool timed) {
+    const gt_graph *g = p->g;
+    hipStream_t s = p->stream;
+    if (p->converged) return GT_OK;  // vp:1025, 1044: nothing visible happens once converged
+    if (p->prm.order == GT_COL) {
+        k_col_counts<<<grid_for(g->ncols_total), TPB, 0, s>>>(g->JA, g->ncols_total, (uint32_t *)p->y);
+        GT_HIP(hipGetLastError());
+        return GT_OK;
+    }
+    if (p->stationary) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        if (p->ev_used + 2 > p->ev.size()) {
+            hipEvent_t a, b;
+            GT_HIP(hipEventCreate(&a)); GT_HIP(hipEventCreate(&b));
+            p->ev.push_back(a); p->ev.push_back(b);
+        }
+        e0 = p->ev[p->ev_used]; e1 = p->ev[p->ev_used + 1]; p->ev_used += 2;
+        GT_HIP(hipEventRecord(e0, s));
+    }
+    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s);
+    if (st != GT_OK) return st;
+    if (timed) GT_HIP(hipEventRecord(e1, s));
+    return GT_OK;
+}
+int gt_program_combine(gt_program *p) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "combine before initialize");
+    return combine_impl(p, false);
+}
+
+int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "apply before initialize");
+    const gt_graph *g = p->g;
+    hipStream_t s = p->stream;
+    const uint32_t nr = g->info.nnzrows, H = g->info.tile_height;
+    if (p->converged) { if (active) *active = 0; return GT_OK; }
+    GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
+    const bool cf = (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF);
+    if (p->iteration == 0 && !cf) k_clear_empty_rows<<<grid_for(H), TPB, 0, s>>>(p->C, g->IJ, H);
+    switch (p->prm.kind) {
+        case GT_DEG:
+            if (p->prm.order == GT_COL) {
+                if (g->info.nnzcols)
+                    k_apply_deg_col<<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)p->y + (uint64_t)g->info.rank * g->info.seg_stride,
+                                                                              g->JC, g->info.nnzcols, p->s0, p->C);
+            } else if (nr) k_apply_deg_row<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C);
+            break;
+        case GT_PR: {
+            int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
+            if (nr) k_apply_pr<<<grid_for(nr), TPB, 0, s>>>((const double *)p->y, g->IR, g->R2C, nr, p->rank, p->C, p->prm.alpha,
+                                                            p->prm.tol, cf, last, p->d_active);
+            break;
+        }
+        case GT_BFS:
+            if (nr) k_apply_bfs<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, p->d_active);
+            break;
+        default:
+            if (nr) k_apply_min<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C, p->d_active);
+            break;
+    }
+    GT_HIP(hipGetLastError());
+    p->iteration++;  // vp:421
+    if (active) {
+        unsigned long long h = 0;
+        GT_HIP(hipMemcpyAsync(&h, p->d_active, sizeof(h), hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        *active = h;
+    }
+    return GT_OK;
+}
+
+int gt_program_finish_converged(gt_program *p) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "finish before initialize");
+    p->converged = true;
+    if (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF && p->g->info.nnzrows) {
+        k_pr_cf_tail<<<grid_for(p->g->info.nnzrows), TPB, 0, p->stream>>>(p->g->IR, p->g->R2C, p->g->info.nnzrows, p->rank, p->prm.alpha);
+        GT_HIP(hipGetLastError());
+    }
+    return GT_OK;
+}
+
+int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(p->g->info.nranks == 1, GT_ERR_STATE,
+               "gt_program_execute runs single-rank graphs; multi-rank runs drive scatter_gather/combine/apply with an exchange of x between them");
+    if (!p->initialized) { int st = init_common(p); if (st != GT_OK) return st; }  // vp:410-411
+    const bool check = (iters == 0);                                               // vp:412-413
+    hipStream_t s = p->stream;
+    p->ev_used = 0;
+    GT_HIP(hipStreamSynchronize(s));
+    auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        st = combine_impl(p, stats != nullptr); if (st != GT_OK) return st;
+        uint64_t active = 0;
+        st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
+        if (check) {
+            if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
+        } else if (p->iteration >= iters) break;
+    }
+    GT_HIP(hipStreamSynchronize(s));
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->iterations = p->iteration; stats->converged = p->converged;
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+            float ms = 0;
+            GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
+            stats->spmv_ms += ms; stats->spmv_launches++;
+        }
+    }
+    return GT_OK;
+}
+
+int gt_program_copy_state(gt_program *p, int field, void *host_out, uint64_t count) {
+    GT_REQUIRE(p && host_out, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(count <= p->g->info.tile_height, GT_ERR_INVALID, "count exceeds tile_height");
+    const void *src = nullptr; uint32_t w = 4;
+    const int k = p->prm.kind;
+    switch (field) {
+        case GT_F_DEGREE: if (k == GT_DEG || k == GT_PR) src = p->s0; break;
+        case GT_F_RANK: if (k == GT_PR) { src = p->rank; w = 8; } break;
+        case GT_F_PARENT: if (k == GT_BFS) src = p->s0; break;
+        case GT_F_HOPS: if (k == GT_BFS) src = p->s1; break;
+        case GT_F_DISTANCE: if (k == GT_SSSP) src = p->s0; break;
+        case GT_F_LABEL: if (k == GT_CC) src = p->s0; break;
+        case GT_F_ACTIVE: src = p->C; w = 1; break;
+        default: break;
+    }
+    GT_REQUIRE(src, GT_ERR_INVALID, "field %d does not exist for program kind %d", field, k);
+    GT_HIP(hipStreamSynchronize(p->stream));
+    GT_HIP(hipMemcpy(host_out, src, count * w, hipMemcpyDeviceToHost));
+    return GT_OK;
+}
+
+int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable) {
+    GT_REQUIRE(p && value_sum && reachable, GT_ERR_INVALID, "null argument");
+    const gt_graph_info &i = p->g->info;
+    const uint32_t H = i.tile_height;
+    const uint64_t base = (uint64_t)i.rank * H;
+    uint64_t s = 0, c = 0;
+    GT_HIP(hipStreamSynchronize(p->stream));
+    if (p->prm.kind == GT_PR) {  // get_state() = rank (pr.h:17), infinity() = 0 (vp:40)
+        std::vector<double> h(H);
+        GT_HIP(hipMemcpy(h.data(), p->rank, (uint64_t)H * 8, hipMemcpyDeviceToHost));
+        for (uint32_t v = 0; v < H; v++)
+            if (h[v] != 0.0 && base + v < i.nrows) { s = (uint64_t)((double)s + h[v]); c++; }
+    } else {
+        const uint32_t inf = (p->prm.kind == GT_DEG) ? 0u : GT_INF;
+        const uint32_t *src = (p->prm.kind == GT_BFS) ? p->s1 : p->s0;  // BFS get_state() = hops (bfs.h:27)
+        std::vector<uint32_t> h(H);
+        GT_HIP(hipMemcpy(h.data(), src, (uint64_t)H * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v = 0; v < H; v++)
+            if (h[v] != inf && base + v < i.nrows) { s += h[v]; c++; }
+    }
+    *value_sum = s; *reachable = c;
+    return GT_OK;
+}
+
+}  // extern "C"

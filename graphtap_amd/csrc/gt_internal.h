@@ -1,0 +1,50 @@
+// gt_internal.h -- shared declarations of the engine's translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/graphtap_amd.h"
+
+void gt_set_error(const char *fmt, ...);
+
+#define GT_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            gt_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return GT_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define GT_REQUIRE(cond, status, ...)                                                       \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            gt_set_error(__VA_ARGS__);                                                      \
+            return (status);                                                                \
+        }                                                                                   \
+    } while (0)
+
+// Owned tile-row of the reference's p x p grid, in HBM.
+struct gt_graph {
+    gt_graph_info info{};
+    gt_graph_flags flags{};
+    // TCSC arrays of the tile-row (ds/compressed_column.hpp:287-296)
+    uint32_t *JA = nullptr;   // [ncols_total + 1]
+    uint32_t *IA = nullptr;   // [nnz_local]
+    uint32_t *A = nullptr;    // [nnz_local] or null
+    uint32_t *JI = nullptr;   // [nnz_local] column id of every entry (edge-parallel kernels)
+    uint32_t *JC = nullptr;   // [nnzcols]   owned segment: compressed col -> local vertex
+    uint32_t *IR = nullptr;   // [nnzrows]   owned segment: compressed row -> local vertex
+    // owned-segment filters (mat/matrix.hpp:861-1122): bit0 = row non-empty (I), bit1 = col non-empty (J)
+    uint8_t *IJ = nullptr;    // [H]
+    uint32_t *IV = nullptr;   // [H] local vertex -> compressed row
+    uint32_t *JV = nullptr;   // [H] local vertex -> compressed col
+    uint32_t *R2C = nullptr;  // [nnzrows] compressed row -> compressed col of the same vertex, or ~0u
+    uint32_t ncols_total = 0; // nranks * seg_stride
+};
+
+int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
+
+// kernels.hip
+int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);

@@ -1,0 +1,292 @@
+// ingest.hip -- device-side graph build: edge records -> owned tile-row in TCSC form.
+//
+// Replaces, for this rank's tile-row, the reference's host pipeline
+//   Graph::parread_binary      src/mat/graph.hpp:308-372   (per-record flags)
+//   Matrix::init_tiles         src/mat/matrix.hpp:538-560  (column-major sort, dedupe)
+//   Matrix::init_filtering     src/mat/matrix.hpp:813-858, 861-1144 (I/IV/J/JV, classes)
+//   TCSC_BASE::populate        src/ds/compressed_column.hpp:371-417
+// with radix sorts / scans (rocPRIM through hipCUB) and a few streaming kernels.
+// Every rank sees the full edge list (replicated ingest) and keeps tile-row `rank`.
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "gt_internal.h"
+
+namespace {
+
+constexpr uint64_t KEY_INVALID = ~0ull;
+constexpr int TPB = 256;
+
+inline unsigned grid_for(uint64_t n, int per_thread = 1) {
+    uint64_t b = (n + (uint64_t)TPB * per_thread - 1) / ((uint64_t)TPB * per_thread);
+    if (b < 1) b = 1;
+    if (b > 256u * 32u) b = 256u * 32u;  // grid-stride the rest
+    return (unsigned)b;
+}
+
+struct DevBuf {  // frees on scope exit: ingest scratch
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+// ---- pass 1: per-record flags, global non-empty bitmaps, localisation -------------------
+// Order of the flag handling is the reference's (graph.hpp:337-356): drop self loop unless
+// self_loops; acyclic swap; transpose swap; insert; mirrored insert when !directed.
+__global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f,
+                         uint32_t nrows, uint32_t H, uint32_t row_lo, uint32_t row_hi,
+                         uint64_t *__restrict__ keys, uint32_t *__restrict__ wts,
+                         uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
+                         unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
+    const int slots = f.directed ? 1 : 2;
+    unsigned long long kept = 0, bad = 0, glob = 0;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t row = rec[e * stride], col = rec[e * stride + 1];
+        uint32_t w = (stride == 3) ? rec[e * stride + 2] : 0;
+        uint64_t k0 = KEY_INVALID, k1 = KEY_INVALID;
+        if (row >= nrows || col >= nrows) {
+            bad++;
+        } else if (!(row == col && !f.self_loops)) {
+            if (f.acyclic && col < row) { uint32_t t = row; row = col; col = t; }
+            if (f.transpose) { uint32_t t = row; row = col; col = t; }
+            rowflag[row] = 1; colflag[col] = 1; glob++;
+            if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; kept++; }
+            if (!f.directed) {
+                rowflag[col] = 1; colflag[row] = 1; glob++;
+                if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; kept++; }
+            }
+        }
+        keys[e * slots] = k0;
+        if (wts) wts[e * slots] = w;
+        if (slots == 2) { keys[e * 2 + 1] = k1; if (wts) wts[e * 2 + 1] = w; }
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_down(kept, o); bad += __shfl_down(bad, o); glob += __shfl_down(glob, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (kept) atomicAdd(&counters[0], kept);
+        if (bad) atomicAdd(&counters[1], bad);
+        if (glob) atomicAdd(&counters[2], glob);
+    }
+}
+
+struct U8ToU32 {
+    __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; }
+};
+
+// ---- dedupe: head flags over the sorted keys (matrix.hpp:545, 553: same row and col) ----
+__global__ void k_head_flags(const uint64_t *__restrict__ keys, uint64_t n, int dedupe, uint32_t *__restrict__ head) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        head[i] = (!dedupe || i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// ---- populate: compressed ids of every kept entry (compressed_column.hpp:382-394) -------
+__global__ void k_populate(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ wts, uint64_t n,
+                           const uint32_t *__restrict__ head, const uint32_t *__restrict__ pos,
+                           const uint32_t *__restrict__ Srow, const uint32_t *__restrict__ Scol,
+                           uint32_t H, uint32_t row_lo, uint32_t seg_stride,
+                           uint32_t *__restrict__ IA, uint32_t *__restrict__ JI, uint32_t *__restrict__ A) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!head[i]) continue;
+        uint32_t o = pos[i];
+        uint32_t row = (uint32_t)keys[i], col = (uint32_t)(keys[i] >> 32);
+        uint32_t seg = col / H;
+        IA[o] = Srow[row] - Srow[row_lo];
+        JI[o] = seg * seg_stride + (Scol[col] - Scol[seg * H]);
+        if (A) A[o] = wts[i];
+    }
+}
+
+// JA[c] = first entry whose column id is >= c (entries are sorted by column id)
+__global__ void k_col_ptr(const uint32_t *__restrict__ JI, uint32_t nnz, uint32_t ncols, uint32_t *__restrict__ JA) {
+    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c <= ncols; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            uint32_t mid = lo + ((hi - lo) >> 1);
+            if (JI[mid] < (uint32_t)c) lo = mid + 1; else hi = mid;
+        }
+        JA[c] = lo;
+    }
+}
+
+// ---- owned-segment filter vectors (matrix.hpp:822-849, 1125-1144) -----------------------
+__global__ void k_segment_vectors(const uint8_t *__restrict__ rowflag, const uint8_t *__restrict__ colflag,
+                                  const uint32_t *__restrict__ Srow, const uint32_t *__restrict__ Scol,
+                                  uint32_t H, uint32_t lo, uint8_t *__restrict__ IJ, uint32_t *__restrict__ IV,
+                                  uint32_t *__restrict__ JV, uint32_t *__restrict__ IR, uint32_t *__restrict__ JC,
+                                  uint32_t *__restrict__ R2C, unsigned int *__restrict__ classes) {
+    unsigned reg = 0, src = 0, snk = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) {
+        uint32_t v = lo + i;
+        uint8_t r = rowflag[v], c = colflag[v];
+        uint32_t iv = Srow[v] - Srow[lo], jv = Scol[v] - Scol[lo];
+        IJ[i] = (uint8_t)(r | (c << 1)); IV[i] = iv; JV[i] = jv;
+        if (r) { IR[iv] = i; R2C[iv] = c ? jv : 0xFFFFFFFFu; }
+        if (c) JC[jv] = i;
+        reg += (r && c); src += (r && !c); snk += (!r && c);
+    }
+    for (int o = 32; o > 0; o >>= 1) { reg += __shfl_down(reg, o); src += __shfl_down(src, o); snk += __shfl_down(snk, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (reg) atomicAdd(&classes[0], reg);
+        if (src) atomicAdd(&classes[1], src);
+        if (snk) atomicAdd(&classes[2], snk);
+    }
+}
+
+}  // namespace
+
+#define ING_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            gt_set_error("ingest: %s failed: %s (line %d)", #call, hipGetErrorString(e_), __LINE__); \
+            return GT_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+#define ING_ALLOC(buf, bytes)                                                                      \
+    do {                                                                                           \
+        if ((buf).alloc(bytes)) { gt_set_error("ingest: out of device memory (%llu bytes)", (unsigned long long)(bytes)); return GT_ERR_HIP; } \
+    } while (0)
+
+int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
+    const gt_graph_flags f = g->flags;
+    const uint32_t p = g->info.nranks, k = g->info.rank, H = g->info.tile_height, nrows = g->info.nrows;
+    const uint64_t span = (uint64_t)p * H;             // vertex slots of the whole grid (>= nrows)
+    const uint32_t row_lo = k * H;
+    const uint32_t row_hi = (uint32_t)(((uint64_t)(k + 1) * H < nrows) ? (uint64_t)(k + 1) * H : nrows);
+    const int stride = weighted ? 3 : 2;
+    const int slots = f.directed ? 1 : 2;
+    const uint64_t cap = m * slots;
+    hipStream_t s = 0;
+
+    DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp;
+    ING_ALLOC(keys, cap * 8); ING_ALLOC(keys2, cap * 8);
+    if (weighted) { ING_ALLOC(wts, cap * 4); ING_ALLOC(wts2, cap * 4); }
+    ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
+    ING_ALLOC(Srow, (span + 1) * 4); ING_ALLOC(Scol, (span + 1) * 4);
+    ING_ALLOC(counters, 8 * sizeof(unsigned long long));
+    ING_HIP(hipMemsetAsync(rowflag.p, 0, span + 1, s));
+    ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
+    ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
+
+    if (m)
+        k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, H, row_lo, row_hi,
+                                             keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr,
+                                             rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
+                                             counters.as<unsigned long long>());
+    unsigned long long hc[3];
+    ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+    ING_HIP(hipStreamSynchronize(s));
+    if (hc[1]) {
+        gt_set_error("%llu edge record(s) name a vertex id > num_vertices=%u (the reference overflows its tile grid silently, "
+                     "src/mat/matrix.hpp:218-220; this library rejects the input)", hc[1], g->info.num_vertices);
+        return GT_ERR_INVALID;
+    }
+    const uint64_t nvalid = hc[0];
+    GT_REQUIRE(nvalid < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED,
+               "tile-row holds %llu entries; column pointers are 32-bit like the reference's Integer_Type "
+               "(src/ds/compressed_column.hpp:294): use more ranks", (unsigned long long)nvalid);
+
+    // exclusive prefix sums of the non-empty flags over the whole grid -> IV / JV of every segment
+    {
+        hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> rin(rowflag.as<const uint8_t>(), U8ToU32());
+        hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> cin(colflag.as<const uint8_t>(), U8ToU32());
+        size_t tb = 0;
+        ING_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, rin, Srow.as<uint32_t>(), span + 1, s));
+        ING_ALLOC(tmp, tb);
+        ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, rin, Srow.as<uint32_t>(), span + 1, s));
+        ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cin, Scol.as<uint32_t>(), span + 1, s));
+    }
+    std::vector<uint32_t> segr(p + 1), segc(p + 1);
+    for (uint32_t q = 0; q <= p; q++) {
+        ING_HIP(hipMemcpyAsync(&segr[q], Srow.as<uint32_t>() + (uint64_t)q * H, 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipMemcpyAsync(&segc[q], Scol.as<uint32_t>() + (uint64_t)q * H, 4, hipMemcpyDeviceToHost, s));
+    }
+    ING_HIP(hipStreamSynchronize(s));
+    uint32_t seg_stride = 0;
+    for (uint32_t q = 0; q < p; q++) seg_stride = std::max(seg_stride, segc[q + 1] - segc[q]);
+    if (seg_stride == 0) seg_stride = 1;
+    g->info.nnzrows = segr[k + 1] - segr[k];
+    g->info.nnzcols = segc[k + 1] - segc[k];
+    g->info.seg_stride = seg_stride;
+    g->info.nnzrows_global = segr[p];
+    g->info.nnzcols_global = segc[p];
+    GT_REQUIRE((uint64_t)p * seg_stride < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "column id space exceeds 32 bits");
+    g->ncols_total = p * seg_stride;
+
+    // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
+    // so that the first copy of a duplicate (row,col) carries its minimum weight. Invalid keys sink
+    // to the end. Radix sort is stable.
+    uint64_t *sorted_keys = keys.as<uint64_t>();
+    uint32_t *sorted_wts = weighted ? wts.as<uint32_t>() : nullptr;
+    if (cap) {
+        size_t tb1 = 0, tb2 = 0;
+        hipcub::DoubleBuffer<uint64_t> dk(keys.as<uint64_t>(), keys2.as<uint64_t>());
+        if (weighted) {
+            hipcub::DoubleBuffer<uint32_t> dw(wts.as<uint32_t>(), wts2.as<uint32_t>());
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, dw, dk, cap, 0, 32, s));
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, dk, dw, cap, 0, 64, s));
+            DevBuf st; ING_ALLOC(st, std::max(tb1, tb2));
+            size_t tb = std::max(tb1, tb2);
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dw, dk, cap, 0, 32, s));   // by weight
+            tb = std::max(tb1, tb2);
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, dw, cap, 0, 64, s));   // then by (col,row)
+            ING_HIP(hipStreamSynchronize(s));
+            sorted_keys = dk.Current(); sorted_wts = dw.Current();
+        } else {
+            ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, dk, cap, 0, 64, s));
+            DevBuf st; ING_ALLOC(st, tb1);
+            ING_HIP(hipcub::DeviceRadixSort::SortKeys(st.p, tb1, dk, cap, 0, 64, s));
+            ING_HIP(hipStreamSynchronize(s));
+            sorted_keys = dk.Current();
+        }
+    }
+
+    // dedupe (only adjacent equal (row,col) exist after the sort) + compaction positions
+    DevBuf head, pos;
+    ING_ALLOC(head, (nvalid + 1) * 4); ING_ALLOC(pos, (nvalid + 1) * 4);
+    uint32_t nnz = 0;
+    if (nvalid) {
+        k_head_flags<<<grid_for(nvalid), TPB, 0, s>>>(sorted_keys, nvalid, !f.parallel_edges, head.as<uint32_t>());
+        size_t tb = 0;
+        ING_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, head.as<uint32_t>(), pos.as<uint32_t>(), nvalid, s));
+        DevBuf st; ING_ALLOC(st, tb);
+        ING_HIP(hipcub::DeviceScan::ExclusiveSum(st.p, tb, head.as<uint32_t>(), pos.as<uint32_t>(), nvalid, s));
+        uint32_t lastpos = 0, lasthead = 0;
+        ING_HIP(hipMemcpyAsync(&lastpos, pos.as<uint32_t>() + (nvalid - 1), 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipMemcpyAsync(&lasthead, head.as<uint32_t>() + (nvalid - 1), 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipStreamSynchronize(s));
+        nnz = lastpos + lasthead;
+    }
+    g->info.nnz_local = nnz;
+    g->info.nnz_global = (p == 1) ? nnz : 0;  // multi-rank: the driver sums nnz_local over ranks
+
+    // persistent arrays
+    auto dmalloc = [&](uint32_t **ptr, uint64_t elems) -> int {
+        return hipMalloc((void **)ptr, (elems ? elems : 1) * sizeof(uint32_t)) == hipSuccess ? 0 : -1;
+    };
+    const uint32_t nr = g->info.nnzrows, nc = g->info.nnzcols;
+    if (dmalloc(&g->IA, nnz) || dmalloc(&g->JI, nnz) || (weighted && dmalloc(&g->A, nnz)) ||
+        dmalloc(&g->JA, (uint64_t)g->ncols_total + 1) || dmalloc(&g->IV, H) || dmalloc(&g->JV, H) ||
+        dmalloc(&g->IR, nr) || dmalloc(&g->JC, nc) || dmalloc(&g->R2C, nr) ||
+        hipMalloc((void **)&g->IJ, H) != hipSuccess) {
+        gt_set_error("ingest: out of device memory for the tile arrays");
+        return GT_ERR_HIP;
+    }
+    if (nvalid)
+        k_populate<<<grid_for(nvalid), TPB, 0, s>>>(sorted_keys, sorted_wts, nvalid, head.as<uint32_t>(), pos.as<uint32_t>(),
+                                                    Srow.as<uint32_t>(), Scol.as<uint32_t>(), H, row_lo, seg_stride,
+                                                    g->IA, g->JI, g->A);
+    k_col_ptr<<<grid_for((uint64_t)g->ncols_total + 1), TPB, 0, s>>>(g->JI, nnz, g->ncols_total, g->JA);
+    unsigned int *classes = (unsigned int *)(counters.as<unsigned long long>() + 4);
+    k_segment_vectors<<<grid_for(H), TPB, 0, s>>>(rowflag.as<uint8_t>(), colflag.as<uint8_t>(), Srow.as<uint32_t>(),
+                                                  Scol.as<uint32_t>(), H, row_lo, g->IJ, g->IV, g->JV, g->IR, g->JC,
+                                                  g->R2C, classes);
+    unsigned int hcl[3];
+    ING_HIP(hipMemcpyAsync(hcl, classes, sizeof(hcl), hipMemcpyDeviceToHost, s));
+    ING_HIP(hipStreamSynchronize(s));
+    ING_HIP(hipGetLastError());
+    g->info.regular = hcl[0]; g->info.source_rows = hcl[1]; g->info.sink_cols = hcl[2];
+    return GT_OK;
+}

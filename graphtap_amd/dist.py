@@ -1,0 +1,51 @@
+"""Multi-GPU iteration driver: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in CPU tests) for the two exchange steps of an iteration.
+
+Partitioning (the a=1 b=p alternative, which is what the reference itself does at
+p=2): rank k owns vertex segment k (height H = nrows/p + 1, src/mat/matrix.hpp:193) and tile-row k
+of the p x p grid. Every iteration
+
+  scatter_gather  rank k computes the messages x_k of ITS non-empty columns   (vp:688-758)
+  exchange        all-gather of the p segments of x                          (replaces the
+                  MPI_Ibcast down column groups, vp:843-862 / 970-1013)
+  combine         local SpMV over tile-row k; y_k is complete, no row-group reduce is needed
+                  (the reference's M6/M7 Isend/Irecv, vp:1083-1111, disappears with a = 1)
+  apply           local                                                       (vp:1610-1802)
+  converged?      all-reduce of one integer                                   (vp:1918)
+
+Degree in _COL_ order (apps/pr.cpp:40-42) accumulates in COLUMN space, where every rank holds a
+partial count: there the accumulators are summed with an all-reduce before apply.
+
+The driver only needs the five methods of a "tile engine"; the product engine is
+vertex_program._HipEngine (C ABI, device buffers); tests drive the same code over gloo."""
+import torch
+import torch.distributed as dist
+
+
+def run(engine, iters, group=None):
+    """Vertex_Program::execute (vp:408-441) across ranks. Returns (iterations, converged)."""
+    check = (iters == 0)
+    p, k, stride = engine.nranks, engine.rank, engine.seg_stride
+    x = engine.x_tensor()               # [p * stride] messages, segment s at [s*stride, (s+1)*stride)
+    mine = x[k * stride:(k + 1) * stride]
+    converged = False
+    while True:
+        engine.scatter_gather()
+        if p > 1 and engine.needs_x_exchange:
+            dist.all_gather_into_tensor(x, mine, group=group)
+        engine.combine()
+        if p > 1 and engine.column_accumulators:
+            dist.all_reduce(engine.y_tensor(), group=group)
+        active = engine.apply(iters, check)
+        if check:
+            if p > 1:
+                t = torch.tensor([active], dtype=torch.int64, device=x.device)
+                dist.all_reduce(t, group=group)
+                active = int(t.item())
+            if active == 0:
+                engine.finish_converged()
+                converged = True
+                break
+        elif engine.iteration >= iters:
+            break
+    return engine.iteration, converged

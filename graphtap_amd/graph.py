@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's Graph<> (src/mat/graph.hpp) over the C ABI.
+
+`Graph.load` keeps the reference's argument list (graph.hpp:41-43) so application code reads
+like src/apps/*.cpp; the graph itself is built and kept in HBM by libgraphtap_amd.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import GraphFlags, GraphInfo, GraphTapError, TileArrays, check, lib
+
+# Tiling_type (src/mat/tiling.hpp:13-16) / Compression_type (src/ds/compressed_column.hpp)
+_2D_, _2DT_ = 0, 1
+_CSC_, _DCSC_, _TCSC_, _TCSC_CF_ = 0, 1, 2, 3
+
+
+def world():
+    """(rank, nranks) of the torch.distributed job if one is initialised, else (0, 1)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def read_edge_file(path, weighted):
+    """Binary edge list as the reference reads it (graph.hpp:308-336): records of two (three with
+    weights) little-endian u32. The reference tells text from binary with popen("file -b")
+    (graph.hpp:119-145); here a file is text when it decodes as ASCII digits/space/comment lines."""
+    size = os.path.getsize(path)
+    stride = 3 if weighted else 2
+    with open(path, "rb") as f:
+        head = f.read(4096)
+    is_text = len(head) > 0 and all((32 <= b < 127) or b in (9, 10, 13) for b in head)
+    if is_text:
+        rows = []
+        with open(path, "r") as f:
+            for line in f:
+                if not line.strip() or line[0] in "#%":   # graph.hpp:208-213
+                    continue
+                parts = line.split()
+                if len(parts) != stride:
+                    raise GraphTapError('read() failure "%s"' % line.strip())  # graph.hpp:250-257
+                rows.append([int(t) for t in parts])
+        return np.asarray(rows, dtype=np.uint32).reshape(-1, stride)
+    if size % (4 * stride) != 0:
+        raise GraphTapError("read() failure: %s is not a whole number of %d-byte records" % (path, 4 * stride))
+    return np.fromfile(path, dtype="<u4").reshape(-1, stride)
+
+
+class Graph:
+    """Graph<Weight, Integer_Type, Fractional_Type> (src/mat/graph.hpp:31-71)."""
+
+    def __init__(self, weighted=False):
+        self.weighted = bool(weighted)   # the reference fixes this at compile time (-DHAS_WEIGHT)
+        self._h = None
+        self.info = None
+        self.flags = None
+        self.compression_type = _TCSC_
+        self.rank, self.nranks = 0, 1
+
+    # -- Graph::load (graph.hpp:105-148)
+    def load(self, filepath, nrows, ncols, directed=True, transpose=False, self_loops=True, acyclic=False,
+             parallel_edges=True, tiling_type=_2DT_, compression_type=_CSC_):
+        edges = read_edge_file(filepath, self.weighted)
+        return self.load_edges(edges, nrows, ncols, directed, transpose, self_loops, acyclic, parallel_edges,
+                               tiling_type, compression_type)
+
+    def load_edges(self, edges, nrows, ncols, directed=True, transpose=False, self_loops=True, acyclic=False,
+                   parallel_edges=True, tiling_type=_2DT_, compression_type=_CSC_, rank=None, nranks=None):
+        """Same as load() for an edge array already in host memory (uint32, shape (m, 2|3))."""
+        edges = np.ascontiguousarray(edges, dtype=np.uint32)
+        stride = 3 if self.weighted else 2
+        if edges.ndim != 2 or edges.shape[1] != stride:
+            raise GraphTapError("edge array must have shape (m, %d)" % stride)
+        return self._build(edges.ctypes.data_as(C.c_void_p), edges.shape[0], 0, nrows, ncols, directed, transpose,
+                           self_loops, acyclic, parallel_edges, compression_type, rank, nranks)
+
+    def load_device(self, dev_ptr, m, nrows, ncols, directed=True, transpose=False, self_loops=True, acyclic=False,
+                    parallel_edges=True, tiling_type=_2DT_, compression_type=_CSC_, rank=None, nranks=None):
+        """Edge records already resident in HBM (bench.py: the synthetic generator writes them there)."""
+        return self._build(C.c_void_p(dev_ptr), m, 1, nrows, ncols, directed, transpose, self_loops, acyclic,
+                           parallel_edges, compression_type, rank, nranks)
+
+    def _build(self, ptr, m, on_device, nrows, ncols, directed, transpose, self_loops, acyclic, parallel_edges,
+               compression_type, rank, nranks):
+        if nrows != ncols:
+            raise GraphTapError("square matrices only (every reference app passes num_vertices twice)")
+        if compression_type not in (_TCSC_, _TCSC_CF_):
+            raise GraphTapError("only TCSC / TCSC_CF tiles exist in this engine (all reference apps use them)")
+        if rank is None:
+            rank, nranks = world()
+        self.free()
+        self.rank, self.nranks = rank, nranks
+        self.compression_type = compression_type
+        self.flags = GraphFlags(int(directed), int(transpose), int(self_loops), int(acyclic), int(parallel_edges))
+        h = C.c_void_p()
+        check(lib().gt_graph_build(C.byref(h), ptr, m, on_device, int(self.weighted), int(nrows),
+                                   C.byref(self.flags), rank, nranks))
+        self._h = h
+        self.info = GraphInfo()
+        check(lib().gt_graph_info_get(self._h, C.byref(self.info)))
+        self.nnz_global = int(self.info.nnz_local)
+        if nranks > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([self.nnz_global], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t)
+            self.nnz_global = int(t.item())
+        return self
+
+    def tile(self):
+        t = TileArrays()
+        check(lib().gt_graph_tile(self._h, C.byref(t)))
+        return t
+
+    def tile_to_host(self):
+        """Copies the owned tile-row's TCSC arrays to numpy (tests compare them with the oracle's)."""
+        t, i = self.tile(), self.info
+        ncols_total = i.nranks * i.seg_stride
+
+        def grab(ptr, n):
+            a = np.zeros(n, np.uint32)
+            if n and ptr:
+                check(lib().gt_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, n * 4))
+            return a
+        return dict(JA=grab(t.JA, ncols_total + 1), IA=grab(t.IA, i.nnz_local),
+                    A=grab(t.A, i.nnz_local) if t.A else None, JC=grab(t.JC, i.nnzcols), IR=grab(t.IR, i.nnzrows))
+
+    # -- Graph::free (graph.hpp:76-81)
+    def free(self):
+        if self._h:
+            check(lib().gt_graph_free(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's Vertex_Program<> surface (src/vp/vertex_program.hpp:23-62)
+and of the five programs in src/apps/{deg,pr,bfs,sssp,cc}.h, over the C ABI.
+
+Same names, argument meaning and call order as the reference, so application code and tests read
+like src/apps/*.cpp:
+
+    G = Graph(); G.load(path, n, n, directed, transpose, self_loops, acyclic, parallel_edges, TT, CT)
+    V = Deg_Program(G, stationary, gather_depends_on_apply, apply_depends_on_iter, _COL_); V.execute(1)
+    VR = PR_Program(G, stationary, ..., _ROW_); VR.initialize(V); VR.execute(20); VR.checksum(); VR.display()
+
+The virtual per-vertex / per-edge hooks of the reference cannot run on a device, so each program is
+an op-code (`kind`) whose hooks are HIP kernels in csrc/engine.hip; there is no CPU path."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import (GT_BFS, GT_CC, GT_COL, GT_DEG, GT_INF, GT_PR, GT_ROW, GT_SSSP, GT_TCSC, GT_TCSC_CF, ExecStats,
+                   GraphTapError, ProgramParams, check, lib)
+from .graph import _TCSC_CF_
+
+_ROW_, _COL_ = GT_ROW, GT_COL   # Ordering_type, vp:17-21
+INF = GT_INF
+
+
+class _CudaArray:
+    """Zero-copy view of engine-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class _HipEngine:
+    """The five phase calls of graphtap_amd.dist.run over the C ABI (device buffers stay in HBM)."""
+
+    def __init__(self, prog):
+        self.prog = prog
+        i = prog.G.info
+        self.rank, self.nranks, self.seg_stride = i.rank, i.nranks, i.seg_stride
+        self.column_accumulators = (prog.ordering_type == _COL_)
+        self.needs_x_exchange = not self.column_accumulators
+        self._x = self._y = None
+
+    def _tensor(self, getter):
+        import torch
+        ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
+        check(getter(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
+        return torch.as_tensor(_CudaArray(ptr.value, n.value, "<f8" if w.value == 8 else "<i4"), device="cuda")
+
+    def x_tensor(self):
+        if self._x is None:
+            self._x = self._tensor(lib().gt_program_x)
+        return self._x
+
+    def y_tensor(self):
+        if self._y is None:
+            self._y = self._tensor(lib().gt_program_y)
+        return self._y
+
+    @property
+    def iteration(self):
+        return self.prog.iteration
+
+    def scatter_gather(self):
+        check(lib().gt_program_scatter_gather(self.prog._h))
+
+    def combine(self):
+        check(lib().gt_program_combine(self.prog._h))
+
+    def apply(self, iters, want_active):
+        a = C.c_uint64(0)
+        check(lib().gt_program_apply(self.prog._h, iters, C.byref(a) if want_active else None))
+        return a.value
+
+    def finish_converged(self):
+        check(lib().gt_program_finish_converged(self.prog._h))
+
+
+class Vertex_Program:
+    """Vertex_Program(Graph&, stationary, gather_depends_on_apply, apply_depends_on_iter, Ordering_type), vp:27-29."""
+    kind = None
+    fields = ()            # (name, gt_field, dtype) of the Vertex_State struct
+    state_field = None     # get_state()
+    infinity = 0           # infinity(), vp:40
+
+    def __init__(self, Graph, stationary=False, gather_depends_on_apply=False, apply_depends_on_iter=False,
+                 ordering_type=_ROW_):
+        if type(self) is Vertex_Program:
+            raise GraphTapError("subclass one of the five programs: device code cannot call user virtuals")
+        self.G = Graph
+        self.stationary = stationary
+        self.gather_depends_on_apply = gather_depends_on_apply
+        self.apply_depends_on_iter = apply_depends_on_iter
+        self.ordering_type = ordering_type
+        self.num_iterations = 0
+        self.converged = False
+        self.root = 0
+        self.alpha, self.tol = 0.15, 1e-5          # pr.h:12-13
+        self.stats = None
+        self._h = None
+        self._already_initialized = False
+        want = self.kind in (GT_DEG, GT_PR)
+        if bool(stationary) != want:
+            raise GraphTapError("%s is %sstationary in the reference (src/apps)" % (type(self).__name__, "" if want else "non-"))
+
+    # -- lazily create the device program (root / alpha / tol are plain members in the reference,
+    #    set after construction: bfs.cpp:46)
+    def _handle(self):
+        if self._h is None:
+            prm = ProgramParams(self.kind, self.ordering_type,
+                                GT_TCSC_CF if self.G.compression_type == _TCSC_CF_ else GT_TCSC,
+                                int(self.root), float(self.alpha), float(self.tol))
+            h = C.c_void_p()
+            check(lib().gt_program_create(C.byref(h), self.G._h, C.byref(prm)))
+            self._h = h
+        return self._h
+
+    @property
+    def iteration(self):
+        it = C.c_uint32()
+        check(lib().gt_program_iteration(self._handle(), C.byref(it)))
+        return it.value
+
+    # -- initialize(), vp:443-464 / initialize(other), vp:466-501
+    def initialize(self, other=None):
+        if other is None:
+            check(lib().gt_program_initialize(self._handle()))
+        else:
+            check(lib().gt_program_initialize_from(self._handle(), other._handle()))
+        self._already_initialized = True
+
+    # -- execute(num_iterations = 0), vp:408-441
+    def execute(self, num_iterations=0):
+        self.num_iterations = int(num_iterations)
+        h = self._handle()
+        if not self._already_initialized:
+            self.initialize()
+        if self.G.nranks == 1:
+            st = ExecStats()
+            check(lib().gt_program_execute(h, self.num_iterations, C.byref(st)))
+            self.stats = st
+            self.converged = bool(st.converged)
+        else:
+            import torch
+            from . import dist as gdist
+            check(lib().gt_program_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            _, self.converged = gdist.run(_HipEngine(self), self.num_iterations)
+        return self
+
+    # -- V, vp:61 (owned segment; struct-of-arrays)
+    @property
+    def V(self):
+        H = self.G.info.tile_height
+        out = {}
+        for name, field, dtype in self.fields:
+            a = np.zeros(H, dtype)
+            check(lib().gt_program_copy_state(self._handle(), field, a.ctypes.data_as(C.c_void_p), H))
+            out[name] = a
+        return out
+
+    def get_vid(self, index):   # vp:1805-1808
+        return index + self.G.info.rank * self.G.info.tile_height
+
+    # -- checksum(), vp:1927-1960 (the accumulator is uint64_t: an fp state truncates at every add)
+    def checksum(self, out=sys.stdout):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().gt_program_checksum(self._handle(), C.byref(a), C.byref(b)))
+        s, cnt = a.value, b.value
+        if self.G.nranks > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([s, cnt], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            s, cnt = int(t[0]), int(t[1])
+        self.value_checksum, self.reachable = s, cnt
+        if self.G.rank == 0 and out is not None:
+            print("Iterations: %d" % self.iteration, file=out)
+            print("Value checksum: %d" % s, file=out)
+            print("Reachable vertices: %d" % cnt, file=out)
+        return s, cnt
+
+    def print_state(self, V, i):
+        raise NotImplementedError
+
+    # -- display(count = 31), vp:2124-2181
+    def display(self, count=31, out=sys.stdout):
+        V = self.V
+        count = min(count, self.G.info.tile_height)
+        lines = ["vertex[%d]:%s" % (self.get_vid(i), self.print_state(V, i)) for i in range(count)]
+        if self.G.rank == 0 and out is not None:
+            print("\n".join(lines), file=out)
+        return lines
+
+    # -- free(), vp:335-405
+    def free(self):
+        if self._h:
+            check(lib().gt_program_free(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _inf_str(v):
+    return "INF" if v == INF else str(int(v))
+
+
+class Deg_Program(Vertex_Program):     # src/apps/deg.h:27-53
+    kind = GT_DEG
+    fields = (("degree", _lib.GT_F_DEGREE, np.uint32),)
+    state_field = "degree"
+
+    def print_state(self, V, i):       # deg.h:24
+        return "Degree=%d" % V["degree"][i]
+
+
+class PR_Program(Vertex_Program):      # src/apps/pr.h:21-48
+    kind = GT_PR
+    fields = (("degree", _lib.GT_F_DEGREE, np.uint32), ("rank", _lib.GT_F_RANK, np.float64))
+    state_field = "rank"
+
+    def print_state(self, V, i):       # pr.h:18
+        return "Rank=%f,Degree=%d" % (V["rank"][i], V["degree"][i])
+
+
+class BFS_Program(Vertex_Program):     # src/apps/bfs.h:33-82
+    kind = GT_BFS
+    fields = (("parent", _lib.GT_F_PARENT, np.uint32), ("hops", _lib.GT_F_HOPS, np.uint32))
+    state_field = "hops"
+    infinity = INF
+
+    def print_state(self, V, i):       # bfs.h:29-30
+        return "Parent=%d,Hops=%s" % (V["parent"][i], _inf_str(V["hops"][i]))
+
+
+class SSSP_Program(Vertex_Program):    # src/apps/sssp.h:29-71
+    kind = GT_SSSP
+    fields = (("distance", _lib.GT_F_DISTANCE, np.uint32),)
+    state_field = "distance"
+    infinity = INF
+
+    def print_state(self, V, i):       # sssp.h:26
+        return "Distance=%s" % _inf_str(V["distance"][i])
+
+
+class CC_Program(Vertex_Program):      # src/apps/cc.h:29-60
+    kind = GT_CC
+    fields = (("label", _lib.GT_F_LABEL, np.uint32),)
+    state_field = "label"
+    infinity = INF
+
+    def print_state(self, V, i):       # cc.h:26
+        return "Label=%d" % V["label"][i]

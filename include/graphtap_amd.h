@@ -1,0 +1,216 @@
+/*
+ * graphtap_amd.h -- C ABI of the MI355X-native SpMV vertex-program engine.
+ *
+ * Drop-in boundary for GraphTap's src/mat + src/vp hot path. The reference has
+ * no FFI of its own (its operator API is the C++ template Vertex_Program<>,
+ * /root/reference/src/vp/vertex_program.hpp:23-209, with virtual per-edge
+ * hooks that cannot run on a device); the seam is therefore one level up: a
+ * graph handle (replaces Graph<>::load + Matrix + Compressed_column) and a
+ * program handle whose hooks are op-codes (replaces Vertex_Program<>::
+ * initialize / execute / V). Each entry point cites what it replaces.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types. Every function
+ * returns GT_OK (0) or a negative gt_status and never calls exit() (the
+ * reference prints to stderr and exits, src/mat/graph.hpp:143-144);
+ * gt_last_error() gives the message of the calling thread's last failure.
+ * Handles are not re-entrant: one caller per handle. All device work of a
+ * handle is ordered on the HIP stream given to gt_set_stream() (default: the
+ * null stream); calls return without waiting for the device unless they copy
+ * to the host or say otherwise.
+ *
+ * include/graphtap_amd.hpp layers Vertex_Program-shaped C++ classes over this
+ * ABI; graphtap_amd/ (Python, ctypes) does the same for tests and bench.py.
+ */
+#ifndef GRAPHTAP_AMD_H
+#define GRAPHTAP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT_ABI_VERSION 1
+#define GT_INF 2147483647u /* apps/bfs.h:12 */
+
+typedef enum gt_status {
+    GT_OK = 0,
+    GT_ERR_INVALID = -1,    /* bad argument / vertex id out of range */
+    GT_ERR_HIP = -2,        /* a HIP runtime call failed */
+    GT_ERR_NO_DEVICE = -3,  /* no gfx950 device visible: the product has no CPU fallback */
+    GT_ERR_UNSUPPORTED = -4,
+    GT_ERR_STATE = -5       /* call order violated */
+} gt_status;
+
+/* program kinds = the reference's five apps (src/apps/{deg,pr,bfs,sssp,cc}.h) */
+typedef enum gt_kind { GT_DEG = 0, GT_PR = 1, GT_BFS = 2, GT_SSSP = 3, GT_CC = 4 } gt_kind;
+/* Ordering_type, vertex_program.hpp:17-21 */
+typedef enum gt_order { GT_ROW = 0, GT_COL = 1 } gt_order;
+/* Compression_type subset used by the apps (TCSC / TCSC_CF), ds/compressed_column.hpp */
+typedef enum gt_compression { GT_TCSC = 0, GT_TCSC_CF = 1 } gt_compression;
+/* generalized SpMV semirings of the five programs (K1/K2/K5 of SURVEY 2.2) */
+typedef enum gt_semiring {
+    GT_PLUS_F64 = 0,     /* y[r] += x[c]            PageRank, pr.h:39-41          */
+    GT_PLUS_U32 = 1,     /* y[r] += x[c]            Degree,   deg.h:43-45         */
+    GT_MIN_U32 = 2,      /* y[r] = min(y, x[c])     BFS / CC, bfs.h:61-63         */
+    GT_MINPLUS_U32 = 3   /* y[r] = min(y, x[c]+w)   SSSP,     sssp.h:48-51        */
+} gt_semiring;
+
+typedef struct gt_graph gt_graph;     /* replaces Graph<> + Matrix<> + tile compressors */
+typedef struct gt_program gt_program; /* replaces Vertex_Program<>                       */
+
+/* Arguments 4-8 of Graph::load (mat/graph.hpp:41-43). */
+typedef struct gt_graph_flags {
+    int32_t directed, transpose, self_loops, acyclic, parallel_edges;
+} gt_graph_flags;
+
+typedef struct gt_graph_info {
+    uint32_t num_vertices;  /* N as passed                                       */
+    uint32_t nrows;         /* N + 1                 (mat/graph.hpp:89-90)        */
+    uint32_t tile_height;   /* H = nrows/p + 1       (mat/matrix.hpp:193)         */
+    uint32_t rank, nranks;  /* this handle holds tile-row `rank` of the p x p grid */
+    uint32_t nnzrows;       /* non-empty rows of the owned segment                */
+    uint32_t nnzcols;       /* non-empty columns of the owned segment             */
+    uint32_t seg_stride;    /* max over segments of nnzcols: x is [nranks][seg_stride] */
+    uint64_t nnz_local;     /* stored entries in this tile-row                    */
+    uint64_t nnz_global;    /* stored entries over all tile-rows (TEPS denominator) */
+    uint64_t nnzrows_global, nnzcols_global;
+    int32_t weighted;
+    uint32_t regular, source_rows, sink_cols; /* owned-segment class counts (matrix.hpp:1125-1144) */
+} gt_graph_info;
+
+/* Device pointers to the owned tile-row in TCSC form (ds/compressed_column.hpp:287-296).
+   Column ids are [segment][compressed col]: c = s * seg_stride + j. */
+typedef struct gt_tile_arrays {
+    const uint32_t *JA; /* [nranks*seg_stride + 1] column pointers              */
+    const uint32_t *IA; /* [nnz_local] compressed row ids                       */
+    const uint32_t *A;  /* [nnz_local] weights, or NULL                         */
+    const uint32_t *JC; /* [nnzcols]  compressed col -> segment-local vertex id */
+    const uint32_t *IR; /* [nnzrows]  compressed row -> segment-local vertex id */
+} gt_tile_arrays;
+
+typedef struct gt_program_params {
+    int32_t kind;        /* gt_kind                                               */
+    int32_t order;       /* gt_order: GT_COL only for GT_DEG (apps/pr.cpp:40)      */
+    int32_t compression; /* gt_compression: only changes PageRank's converge mode  */
+    uint32_t root;       /* BFS / SSSP root (bfs.cpp:46)                           */
+    double alpha;        /* pr.h:13 (0.15)                                         */
+    double tol;          /* pr.h:12 (1e-5)                                         */
+} gt_program_params;
+
+typedef struct gt_exec_stats {
+    uint32_t iterations;   /* value of Vertex_Program::iteration after the call   */
+    uint32_t converged;
+    double seconds;        /* wall time of the iteration loop, device drained ("Execute time", vp:416-437) */
+    double spmv_ms;        /* sum of SpMV kernel durations (HIP events on the handle's stream) */
+    uint32_t spmv_launches;
+    uint32_t reserved;
+} gt_exec_stats;
+
+/* state fields for gt_program_copy_state */
+typedef enum gt_field {
+    GT_F_DEGREE = 0,  /* u32  Deg_State::degree / PR_State::degree (deg.h:21-25) */
+    GT_F_RANK = 1,    /* f64  PR_State::rank (pr.h:15-19)                        */
+    GT_F_PARENT = 2,  /* u32  BFS_State::parent (bfs.h:23-31)                    */
+    GT_F_HOPS = 3,    /* u32  BFS_State::hops                                    */
+    GT_F_DISTANCE = 4,/* u32  SSSP_State::distance (sssp.h:21-25)                */
+    GT_F_LABEL = 5,   /* u32  CC_State::label (cc.h:21-25)                       */
+    GT_F_ACTIVE = 6   /* u8   Vertex_Program::C (vp:161)                         */
+} gt_field;
+
+/* ---- library ---------------------------------------------------------- */
+int gt_abi_version(void);
+const char *gt_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int gt_device_count(void);
+/* Binds the calling thread to HIP device `device` (one process per GPU: LOCAL_RANK). */
+int gt_set_device(int device);
+
+/* ---- graph: replaces Graph::load (mat/graph.hpp:105-148) ---------------
+ * edges: m records <u4 row, u4 col[, u4 weight]> exactly as in the reference's
+ * binary files (ds/triple.hpp:10-13), in host memory or (edges_on_device != 0)
+ * already in HBM. The per-record flag handling, per-tile sort/dedupe, the
+ * non-empty row/column filters and the TCSC build all run on the device
+ * (replaces parread_binary :308-372, Matrix::init_tiles matrix.hpp:538-560,
+ * init_filtering :813-858 and TCSC_BASE::populate compressed_column.hpp:371-417).
+ * rank/nranks: the handle keeps tile-row `rank` of the reference's nranks x nranks
+ * grid (1-D row partition, a=1 b=p of SURVEY 8e); every rank passes the SAME
+ * full edge list. The caller may free `edges` after the call returns. */
+int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                   uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks);
+int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
+int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
+/* Graph::free (mat/graph.hpp:76-81). Programs borrow the graph: free them first. */
+int gt_graph_free(gt_graph *g);
+
+/* ---- programs: replaces Vertex_Program<> ------------------------------ */
+/* ctor, vertex_program.hpp:214-330 (stationary / gather_depends_on_apply /
+ * apply_depends_on_iter are implied by `kind` exactly as the apps set them). */
+int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *params);
+/* initialize(), vp:443-464 */
+int gt_program_initialize(gt_program *p);
+/* initialize(other), vp:466-501: PageRank takes Deg's degrees where the row is non-empty */
+int gt_program_initialize_from(gt_program *p, const gt_program *other);
+/* execute(n), vp:408-441; iters == 0 runs until converged. Single-rank graphs only
+ * (nranks == 1); multi-rank runs drive the three phases below with an exchange between them. */
+int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats);
+/* Work of every later call on this handle is ordered on `hip_stream` (a hipStream_t). */
+int gt_program_set_stream(gt_program *p, void *hip_stream);
+
+/* phase level, for the multi-GPU driver (graphtap_amd/dist.py) ------------
+ * x is one device buffer of nranks*seg_stride messages (f64 for PageRank, u32
+ * otherwise), segment s at [s*seg_stride, (s+1)*seg_stride). The engine owns a
+ * default buffer; a caller that exchanges through its own allocation (a torch
+ * tensor handed to RCCL) installs it with gt_program_set_x. */
+int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
+int gt_program_set_x(gt_program *p, void *dev_ptr);
+/* scatter_gather(), vp:639-758 without the broadcast: fills the OWNED segment of x */
+int gt_program_scatter_gather(gt_program *p);
+/* combine(), vp:1017-1113 for the local tile-row (all column segments of x must be current) */
+int gt_program_combine(gt_program *p);
+/* apply(), vp:1610-1802, then iteration++. active (nullable) receives the number of
+ * owned vertices whose applicator returned true -- the local term of has_converged(),
+ * vp:1885-1923 (regular rows only under GT_TCSC_CF); reading it waits for the stream. */
+int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active);
+/* the `converged` tail of execute(), vp:425-428 (only PageRank under GT_TCSC_CF is affected) */
+int gt_program_finish_converged(gt_program *p);
+int gt_program_iteration(const gt_program *p, uint32_t *iteration);
+/* In GT_COL order (Deg in apps/pr.cpp) the accumulators live in column space and every
+ * rank holds a partial sum; the driver sums them across ranks (the reference's
+ * row-group reduce M6, vp:1083-1111) before apply. */
+int gt_program_y(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
+
+/* V, vp:61: copies `count` (<= tile_height) entries of the owned segment to the host */
+int gt_program_copy_state(gt_program *p, int field, void *host_out, uint64_t count);
+/* checksum(), vp:1927-1960, local part: sum of get_state() and count over owned vertices with
+ * state != infinity() and vid < nrows. The reference's accumulator is uint64_t and is `+=`'d with
+ * the state, so a double state truncates at EVERY add ("Value checksum: 70" for a true 317.02). */
+int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable);
+/* free(), vp:335-405 */
+int gt_program_free(gt_program *p);
+
+/* ---- kernel-level seam: spmv_stationary / spmv_nonstationary -----------
+ * (vp:1116-1327, 1438-1506) y = A (x) x over the handle's tile-row, device pointers.
+ * x: nranks*seg_stride elements, y: nnzrows elements, both of the semiring's type;
+ * y is accumulated into (the caller zero/INF-fills it). Columns whose message is
+ * GT_INF are skipped under the two min semirings (vp:1492). */
+int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream);
+
+/* ---- synthetic input (no generator in the reference) --------
+ * Writes records [first, first+count) of the counter-based R-MAT stream
+ * (graphtap_amd/rmat.py is the bit-identical host version) to device memory. */
+int gt_rmat_generate(void *dev_out, int scale, uint64_t seed, int weighted, uint64_t first, uint64_t count,
+                     void *hip_stream);
+
+/* ---- small device helpers so ctypes callers need no HIP binding -------- */
+int gt_malloc(void **dev_ptr, uint64_t bytes);
+int gt_free(void *dev_ptr);
+int gt_memcpy_h2d(void *dev_dst, const void *host_src, uint64_t bytes);
+int gt_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes);
+int gt_memset(void *dev_ptr, int value, uint64_t bytes);
+int gt_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHTAP_AMD_H */

@@ -1,0 +1,393 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (graphtap_amd's ctypes mirror of
+include/graphtap_amd.h), against (a) the golden vectors produced by the unmodified reference and
+(b) the CPU oracle on the same seeded inputs. Integer programs bit-exact; PageRank within the
+north-star tolerance of 1e-6 relative (fp64 atomics re-associate the sums).
+
+Tests read like src/apps/*.cpp on purpose."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+PR_RTOL = 1e-6   # BASELINE.json north_star: "within 1e-6 relative for PageRank ranks"
+
+
+@pytest.fixture(scope="module")
+def gt():
+    import graphtap_amd as gt
+    gt._lib.require_gpu()          # fails loudly: there is no CPU fallback
+    gt._lib.check(gt._lib.lib().gt_set_device(0))
+    return gt
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def run_pr(gt, edges, nv, iters, cf=True):
+    """apps/pr.cpp:23-54 (cf) / apps/pr1.cpp (plain TCSC)."""
+    G = gt.Graph()
+    G.load_edges(edges, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_ if cf else gt._TCSC_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_)
+    V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_)
+    VR.initialize(V)
+    V.free()
+    VR.execute(iters)
+    out = dict(VR.V, iterations=VR.iteration, checksum=VR.checksum(out=None), stats=VR.stats, nnz=G.info.nnz_local)
+    VR.free(); G.free()
+    return out
+
+
+def run_min(gt, app, edges, nv, root=0):
+    """apps/bfs.cpp, apps/sssp.cpp, apps/cc.cpp."""
+    if app == "bfs":
+        G = gt.Graph(); G.load_edges(edges, nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = root
+    elif app == "sssp":
+        G = gt.Graph(weighted=True); G.load_edges(edges, nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.SSSP_Program(G, False, True, False, gt._ROW_); P.root = root
+    else:
+        G = gt.Graph(); G.load_edges(edges, nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.CC_Program(G, False, True, False, gt._ROW_)
+    P.execute()
+    out = dict(P.V, iterations=P.iteration, checksum=P.checksum(out=None), display=P.display(out=None))
+    P.free(); G.free()
+    return out
+
+
+# ------------------------------------------------------------------------------- ingest
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("app", ["deg", "pr", "bfs", "sssp", "cc"])
+def test_ingest_builds_the_oracles_tcsc(gt, O, name, app):
+    c = load_case(name)
+    weighted = (app == "sssp")
+    e = c["wedges"] if weighted else c["edges"]
+    f = O.APP_FLAGS[app]
+    og = O.OracleGraph(e, c["num_vertices"], weighted=weighted, **f)
+    G = gt.Graph(weighted=weighted)
+    G.load_edges(e, c["num_vertices"], c["num_vertices"], f["directed"], f["transpose"], f["self_loops"], f["acyclic"],
+                 f["parallel_edges"], gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    i = G.info
+    assert (i.nnz_local, i.nnzrows, i.nnzcols, i.tile_height, i.nrows) == (og.nnz, og.nnzrows, og.nnzcols, og.H, og.nrows)
+    assert i.seg_stride == max(og.nnzcols, 1)
+    cc = og.class_counts()
+    assert (i.regular, i.source_rows, i.sink_cols) == (cc["regular"], cc["source_rows"], cc["sink_cols"])
+    t = G.tile_to_host()
+    assert (t["JA"][:og.nnzcols + 1] == og.JA).all() and (t["IA"] == og.IA).all()
+    assert (t["JC"] == og.JC).all() and (t["IR"] == og.IR).all()
+    if weighted:
+        assert (t["A"] == og.A).all()
+    G.free()
+
+
+def test_ingest_edge_cases(gt, O):
+    # empty edge list
+    G = gt.Graph(); G.load_edges(np.zeros((0, 2), np.uint32), 10, 10, True, True, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    assert (G.info.nnz_local, G.info.nnzrows, G.info.nnzcols, G.info.tile_height) == (0, 0, 0, 12)
+    P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+    assert (P.V["label"] == np.arange(12)).all() and P.iteration == 1
+    P.free(); G.free()
+    # only self loops, dropped by the BFS flags -> empty graph, root reaches nothing else
+    e = np.array([[3, 3], [4, 4]], np.uint32)
+    G = gt.Graph(); G.load_edges(e, 8, 8, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    assert G.info.nnz_local == 0
+    P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = 3; P.execute()
+    r = O.run_app("bfs", e, 8, root=3)
+    assert (P.V["hops"] == r["hops"]).all() and (P.V["parent"] == r["parent"]).all() and P.iteration == r["iterations"]
+    P.free(); G.free()
+    # the maximum id N itself is a legal vertex (nrows = N + 1); N + 1 is not
+    e = np.array([[0, 8], [8, 0]], np.uint32)
+    G = gt.Graph(); G.load_edges(e, 8, 8, True, True, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    assert G.info.nnz_local == 2
+    G.free()
+    with pytest.raises(gt.GraphTapError, match="vertex id"):
+        gt.Graph().load_edges(np.array([[0, 9]], np.uint32), 8, 8, True, True, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    # acyclic flag (graph.hpp:343-346)
+    c = load_case("rmat8")
+    og = O.OracleGraph(c["edges"], 256, directed=True, transpose=False, self_loops=False, acyclic=True, parallel_edges=False)
+    G = gt.Graph(); G.load_edges(c["edges"], 256, 256, True, False, False, True, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    t = G.tile_to_host()
+    assert G.info.nnz_local == og.nnz and (t["IA"] == og.IA).all() and (t["JA"][:og.nnzcols + 1] == og.JA).all()
+    G.free()
+
+
+def test_device_rmat_generator_matches_host(gt):
+    from graphtap_amd.rmat import rmat_edges
+    L = gt._lib.lib()
+    for weighted in (False, True):
+        host = rmat_edges(14, 16, seed=3, weighted=weighted, first=1000, count=100000)
+        d = C.c_void_p(); gt._lib.check(L.gt_malloc(C.byref(d), host.nbytes))
+        gt._lib.check(L.gt_rmat_generate(d, 14, 3, int(weighted), 1000, 100000, None))
+        got = np.zeros_like(host); gt._lib.check(L.gt_memcpy_d2h(got.ctypes.data_as(C.c_void_p), d, host.nbytes))
+        gt._lib.check(L.gt_free(d))
+        assert (got == host).all()
+
+
+# ------------------------------------------------------------------------------- kernel-level SpMV
+@pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
+def test_spmv_kernels_match_oracle(gt, O, name):
+    c = load_case(name)
+    L = gt._lib.lib()
+    rng = np.random.RandomState(11)
+
+    def dev(a):
+        d = C.c_void_p(); gt._lib.check(L.gt_malloc(C.byref(d), max(a.nbytes, 1)))
+        gt._lib.check(L.gt_memcpy_h2d(d, a.ctypes.data_as(C.c_void_p), a.nbytes)); return d
+
+    def host(d, like):
+        o = np.zeros_like(like); gt._lib.check(L.gt_memcpy_d2h(o.ctypes.data_as(C.c_void_p), d, o.nbytes)); return o
+
+    f = O.APP_FLAGS["pr"]
+    og = O.OracleGraph(c["edges"], c["num_vertices"], **f)
+    G = gt.Graph(); G.load_edges(c["edges"], c["num_vertices"], c["num_vertices"], True, True, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    x = rng.rand(og.nnzcols); y0 = rng.rand(og.nnzrows)
+    want = og.spmv_plus_f64(x, y0.copy())
+    dx, dy = dev(x), dev(y0)
+    gt._lib.check(L.gt_spmv(G._h, gt._lib.GT_PLUS_F64, dx, dy, None))
+    got = host(dy, y0)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    L.gt_free(dx); L.gt_free(dy); G.free()
+
+    f = O.APP_FLAGS["sssp"]
+    og = O.OracleGraph(c["wedges"], c["num_vertices"], weighted=True, **f)
+    G = gt.Graph(weighted=True); G.load_edges(c["wedges"], c["num_vertices"], c["num_vertices"], True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    x = rng.randint(0, 1000, og.nnzcols).astype(np.uint32); x[rng.rand(og.nnzcols) < 0.5] = gt.INF
+    y0 = rng.randint(0, 2000, og.nnzrows).astype(np.uint32); y0[rng.rand(og.nnzrows) < 0.5] = gt.INF
+    for sr, ograph in ((gt._lib.GT_MINPLUS_U32, og),):
+        want = ograph.spmv_min_u32(x, y0.copy())
+        dx, dy = dev(x), dev(y0)
+        gt._lib.check(L.gt_spmv(G._h, sr, dx, dy, None))
+        assert (host(dy, y0) == want).all()
+        L.gt_free(dx); L.gt_free(dy)
+    G.free()
+
+
+# ------------------------------------------------------------------------------- the five apps vs the reference
+@pytest.mark.parametrize("name", CASES)
+def test_deg_app_matches_reference(gt, name, known_answers):
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, False, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)   # deg.cpp:27-35
+    V = gt.Deg_Program(G, True, False, False, gt._ROW_); V.execute(1)
+    assert (V.V["degree"][:n] == c["np1_deg_a"]).all()
+    ka = known_answers[name]["np1_deg"]
+    assert V.checksum(out=None) == (ka["checksum"], ka["reachable"]) and V.iteration == 1
+    V.free(); G.free()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("iters", [1, 3, 20])
+def test_pagerank_matches_reference(gt, name, iters, known_answers):
+    c = load_case(name); n = c["num_vertices"] + 1
+    key = "np1_pr%d" % iters
+    for cf in (True, False):
+        r = run_pr(gt, c["edges"], c["num_vertices"], iters, cf)
+        assert r["iterations"] == iters
+        assert (r["degree"][:n] == c[key + "_a"]).all()
+        ref = c[key + "_c"]
+        rel = np.abs(r["rank"][:n] - ref) / ref
+        assert rel.max() < PR_RTOL, rel.max()
+    ka = known_answers[name][key]
+    assert r["checksum"][1] == ka["reachable"] and abs(r["checksum"][0] - ka["checksum"]) <= 1  # truncating sum: order-sensitive by 1 ulp cases
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pagerank_converge_mode_matches_reference(gt, name, known_answers):
+    c = load_case(name); n = c["num_vertices"] + 1
+    for cf, key in ((False, "np1_prconv_tcsc"), (True, "np1_prconv_cf")):
+        r = run_pr(gt, c["edges"], c["num_vertices"], 0, cf)
+        assert r["iterations"] == known_answers[name][key]["iterations"]
+        ref = c[key + "_c"]
+        assert (np.abs(r["rank"][:n] - ref) / ref).max() < PR_RTOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bfs_sssp_cc_bit_exact(gt, name, known_answers):
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    roots = [(c["root"], "")] + ([(0, "0")] if c["root"] != 0 and "np1_bfs0_a" in c else [])
+    for root, sfx in roots:
+        r = run_min(gt, "bfs", c["edges"], nv, root)
+        assert (r["parent"][:n] == c["np1_bfs%s_a" % sfx]).all() and (r["hops"][:n] == c["np1_bfs%s_b" % sfx]).all()
+        ka = known_answers[name]["np1_bfs" + sfx]
+        assert (r["iterations"], r["checksum"]) == (ka["iterations"], (ka["checksum"], ka["reachable"]))
+        r = run_min(gt, "sssp", c["wedges"], nv, root)
+        assert (r["distance"][:n] == c["np1_sssp%s_a" % sfx]).all()
+        ka = known_answers[name]["np1_sssp" + sfx]
+        assert (r["iterations"], r["checksum"]) == (ka["iterations"], (ka["checksum"], ka["reachable"]))
+    r = run_min(gt, "cc", c["edges"], nv)
+    assert (r["label"][:n] == c["np1_cc_a"]).all()
+    ka = known_answers[name]["np1_cc"]
+    assert (r["iterations"], r["checksum"]) == (ka["iterations"], (ka["checksum"], ka["reachable"]))
+
+
+def test_display_lines_match_survey_table(gt):
+    """First states printed by the reference on its bundled sample."""
+    c = load_case("rmat10")
+    r = run_min(gt, "bfs", c["edges"], 1024, 0)
+    assert r["display"][1:6] == ["vertex[1]:Parent=317,Hops=2", "vertex[2]:Parent=151,Hops=2", "vertex[3]:Parent=345,Hops=2",
+                                 "vertex[4]:Parent=151,Hops=2", "vertex[5]:Parent=866,Hops=3"]
+    r = run_min(gt, "sssp", c["wedges"], 1024, 0)
+    assert r["display"][1:6] == ["vertex[1]:Distance=43", "vertex[2]:Distance=INF", "vertex[3]:Distance=INF",
+                                 "vertex[4]:Distance=51", "vertex[5]:Distance=INF"]
+    G = gt.Graph(); G.load_edges(c["edges"], 1024, 1024, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V); VR.execute(20)
+    d = VR.display(out=None)
+    assert d[0] == "vertex[0]:Rank=0.165455,Degree=10" and d[3] == "vertex[3]:Rank=0.151325,Degree=0" and d[5] == "vertex[5]:Rank=0.150000,Degree=0"
+    assert len(d) == 31
+    VR.free(); V.free(); G.free()
+
+
+# ------------------------------------------------------------------------------- mid-size vs the oracle
+@pytest.mark.parametrize("scale,seed", [(16, 1), (18, 2)])
+def test_midsize_rmat_against_oracle(gt, O, scale, seed):
+    from graphtap_amd.rmat import rmat_edges
+    nv = 1 << scale
+    w = rmat_edges(scale, 16, seed, weighted=True); e = np.ascontiguousarray(w[:, :2])
+    ref = O.run_app("pr", e, nv, iters=20)
+    r = run_pr(gt, e, nv, 20)
+    assert (r["degree"] == ref["degree"]).all()
+    assert (np.abs(r["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+    root = int(np.bincount(e[:, 0]).argmax())
+    ref = O.run_app("bfs", e, nv, root=root); r = run_min(gt, "bfs", e, nv, root)
+    assert (r["parent"] == ref["parent"]).all() and (r["hops"] == ref["hops"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("cc", e, nv); r = run_min(gt, "cc", e, nv)
+    assert (r["label"] == ref["label"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("sssp", w, nv, root=root); r = run_min(gt, "sssp", w, nv, root)
+    assert (r["distance"] == ref["distance"]).all() and r["iterations"] == ref["iterations"]
+
+
+# ------------------------------------------------------------------------------- multi-rank layout on one GPU
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
+def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks):
+    """Every rank's tile-row on the same GPU, with the all-gather of x done by device copies: checks
+    the p-rank data layout (H = nrows/p + 1, [segment][seg_stride] columns, owned-segment state)
+    of the engine without RCCL. BFS labels must equal the reference's np=1 run bit for bit;
+    PageRank within 1e-6 (the reference's own np>1 runs differ from np=1 by fp association too)."""
+    import torch
+    from graphtap_amd import dist as gdist
+    from graphtap_amd.vertex_program import _HipEngine
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+
+    class Loopback:
+        """dist.run's collectives replaced by copies between the p engines living in this process."""
+
+    def run_all(make):
+        progs = [make(r) for r in range(nranks)]
+        engs = [_HipEngine(p) for p in progs]
+        for p in progs:
+            p.initialize() if not p._already_initialized else None
+        return progs, engs
+
+    def lockstep(progs, engs, iters):
+        check = iters == 0
+        stride = engs[0].seg_stride
+        while True:
+            for e_ in engs: e_.scatter_gather()
+            if engs[0].needs_x_exchange:
+                xs = [e_.x_tensor() for e_ in engs]
+                for r, xr in enumerate(xs):
+                    for q, xq in enumerate(xs):
+                        if q != r: xq[r * stride:(r + 1) * stride].copy_(xr[r * stride:(r + 1) * stride])
+            for e_ in engs: e_.combine()
+            if engs[0].column_accumulators:
+                tot = sum(e_.y_tensor().clone() for e_ in engs)
+                for e_ in engs: e_.y_tensor().copy_(tot)
+            act = sum(e_.apply(iters, check) for e_ in engs)
+            if check:
+                if act == 0:
+                    for e_ in engs: e_.finish_converged()
+                    break
+            elif engs[0].iteration >= iters:
+                break
+
+    def gather(progs, field):
+        H = progs[0].G.info.tile_height
+        full = np.concatenate([p.V[field] for p in progs])
+        assert full.size == nranks * H
+        return full[:n]
+
+    # BFS
+    graphs = []
+    def mk_bfs(r):
+        G = gt.Graph(); G.load_edges(c["edges"], nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks)
+        graphs.append(G)
+        P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = c["root"]; P.initialize(); return P
+    progs, engs = run_all(mk_bfs)
+    assert sum(G.info.nnz_local for G in graphs) == load_nnz(gt, c, "bfs")
+    lockstep(progs, engs, 0)
+    assert (gather(progs, "parent") == c["np1_bfs_a"]).all() and (gather(progs, "hops") == c["np1_bfs_b"]).all()
+    for p in progs: p.free()
+    for G in graphs: G.free()
+    # Deg(_COL_) + PageRank, apps/pr.cpp
+    graphs = []
+    def mk_deg(r):
+        G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=r, nranks=nranks)
+        graphs.append(G)
+        P = gt.Deg_Program(G, True, False, False, gt._COL_); P.initialize(); return P
+    degs, dengs = run_all(mk_deg)
+    lockstep(degs, dengs, 1)
+    prs = []
+    for r in range(nranks):
+        P = gt.PR_Program(graphs[r], True, False, False, gt._ROW_); P.initialize(degs[r]); prs.append(P)
+    pengs = [_HipEngine(p) for p in prs]
+    lockstep(prs, pengs, 20)
+    assert (gather(prs, "degree") == c["np1_pr20_a"]).all()
+    ref = c["np1_pr20_c"]
+    assert (np.abs(gather(prs, "rank") - ref) / ref).max() < PR_RTOL
+    for p in prs + degs: p.free()
+    for G in graphs: G.free()
+    torch.cuda.synchronize()
+
+
+def load_nnz(gt, c, app):
+    from oracle import oracle as O
+    return O.OracleGraph(c["edges"], c["num_vertices"], **O.APP_FLAGS[app]).nnz
+
+
+# ------------------------------------------------------------------------------- full-size properties
+def test_pagerank_rmat22_properties(gt):
+    """BASELINE config 2 size (RMAT-22, 67 M edges, 20 iterations): too large for the oracle in a test,
+    so check size-independent properties: (i) the SpMV conserves mass, sum(y) = sum_j x[j] * colcount[j];
+    (ii) ranks of rows without in-edges stay alpha; (iii) determinism of the degree pass;
+    (iv) all ranks >= alpha and finite."""
+    import torch
+    L = gt._lib.lib()
+    scale, nv = 22, 1 << 22
+    m = 16 << scale
+    d = C.c_void_p(); gt._lib.check(L.gt_malloc(C.byref(d), m * 8))
+    gt._lib.check(L.gt_rmat_generate(d, scale, 1, 0, 0, m, None))
+    G = gt.Graph(); G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    gt._lib.check(L.gt_free(d))
+    assert G.info.nnz_local == m
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V)
+    deg = V.V["degree"]
+    assert int(deg.astype(np.int64).sum()) == m
+    VR.execute(20)
+    st = VR.V
+    rank, degree = st["rank"], st["degree"]
+    assert np.isfinite(rank).all() and rank.min() >= 0.15 - 1e-15
+    t = G.tile_to_host()
+    has_row = np.zeros(G.info.tile_height, bool); has_row[t["IR"]] = True
+    assert (rank[~has_row] == 0.15).all() and (degree[~has_row] == 0).all()
+    # mass conservation of one more SpMV, checked in fp64 on the host
+    x = np.zeros(G.info.nnzcols); v = t["JC"]; nz = degree[v] > 0
+    x[nz] = rank[v][nz] / degree[v][nz]
+    colcount = np.diff(t["JA"][:G.info.nnzcols + 1].astype(np.int64))
+    dx = C.c_void_p(); dy = C.c_void_p()
+    gt._lib.check(L.gt_malloc(C.byref(dx), x.nbytes)); gt._lib.check(L.gt_malloc(C.byref(dy), G.info.nnzrows * 8))
+    gt._lib.check(L.gt_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes)); gt._lib.check(L.gt_memset(dy, 0, G.info.nnzrows * 8))
+    gt._lib.check(L.gt_spmv(G._h, gt._lib.GT_PLUS_F64, dx, dy, None))
+    y = np.zeros(G.info.nnzrows); gt._lib.check(L.gt_memcpy_d2h(y.ctypes.data_as(C.c_void_p), dy, y.nbytes))
+    assert abs(y.sum() - (x * colcount).sum()) <= 1e-9 * y.sum()
+    # the applied ranks are alpha + 0.85 * y of the previous iteration's x, so this y reproduces iteration 21
+    L.gt_free(dx); L.gt_free(dy)
+    VR.free(); V.free(); G.free()
