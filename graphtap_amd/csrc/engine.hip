@@ -52,6 +52,7 @@ struct gt_program {
     unsigned long long *d_active = nullptr;
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
+    bool timing = false;
 };
 
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
@@ -456,7 +457,24 @@ static int combine_impl(gt_program *p, bool timed) {
 }
 int gt_program_combine(gt_program *p) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "combine before initialize");
-    return combine_impl(p, false);
+    return combine_impl(p, p->timing);
+}
+int gt_program_enable_timing(gt_program *p, int on) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    p->timing = on != 0;
+    return GT_OK;
+}
+int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int reset) {
+    GT_REQUIRE(p && spmv_ms && launches, GT_ERR_INVALID, "null argument");
+    GT_HIP(hipStreamSynchronize(p->stream));
+    *spmv_ms = 0; *launches = 0;
+    for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+        float ms = 0;
+        GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
+        *spmv_ms += ms; (*launches)++;
+    }
+    if (reset) p->ev_used = 0;
+    return GT_OK;
 }
 
 int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {

@@ -104,7 +104,7 @@ class Graph:
         self.info = GraphInfo()
         check(lib().gt_graph_info_get(self._h, C.byref(self.info)))
         self.nnz_global = int(self.info.nnz_local)
-        if nranks > 1:
+        if nranks > 1 and world()[1] == nranks:   # explicit rank/nranks without a process group: caller sums
             import torch
             import torch.distributed as dist
             t = torch.tensor([self.nnz_global], dtype=torch.int64)

@@ -156,6 +156,13 @@ int gt_program_initialize_from(gt_program *p, const gt_program *other);
 int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats);
 /* Work of every later call on this handle is ordered on `hip_stream` (a hipStream_t). */
 int gt_program_set_stream(gt_program *p, void *hip_stream);
+/* SpMV kernel timing with HIP events recorded on the handle's stream around every SpMV launch of
+ * gt_program_combine (the "-DTIMING" combine record of the reference, vp:2134-2152, at kernel
+ * granularity). gt_program_timing waits for the stream, returns the sum of the durations and the
+ * number of launches since the last reset, and optionally resets. gt_program_execute fills the
+ * same numbers into gt_exec_stats by itself. */
+int gt_program_enable_timing(gt_program *p, int on);
+int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int reset);
 
 /* phase level, for the multi-GPU driver (graphtap_amd/dist.py) ------------
  * x is one device buffer of nranks*seg_stride messages (f64 for PageRank, u32
