@@ -11,6 +11,7 @@ GT_DEG, GT_PR, GT_BFS, GT_SSSP, GT_CC = range(5)
 GT_ROW, GT_COL = 0, 1
 GT_TCSC, GT_TCSC_CF = 0, 1
 GT_PLUS_F64, GT_PLUS_U32, GT_MIN_U32, GT_MINPLUS_U32 = range(4)
+GT_SPMV_EDGE, GT_SPMV_PB = 0, 1
 GT_F_DEGREE, GT_F_RANK, GT_F_PARENT, GT_F_HOPS, GT_F_DISTANCE, GT_F_LABEL, GT_F_ACTIVE = range(7)
 
 
@@ -53,6 +54,7 @@ SIGNATURES = {
     "gt_set_device": (C.c_int, [C.c_int]),
     "gt_graph_build": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int]),
     "gt_graph_info_get": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
+    "gt_graph_select_spmv": (C.c_int, [_vp, C.c_int]),
     "gt_graph_tile": (C.c_int, [_vp, C.POINTER(TileArrays)]),
     "gt_graph_free": (C.c_int, [_vp]),
     "gt_program_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(ProgramParams)]),

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -239,6 +240,7 @@ int gt_graph_free(gt_graph *g) {
     if (!g) return GT_OK;
     void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    gt_pb_free(g->pb);
     delete g;
     return GT_OK;
 }
@@ -268,7 +270,24 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     int st = gt_ingest(g, dev_edges, m, weighted);
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_graph_free(g); return st; }
+    const char *env = getenv("GRAPHTAP_SPMV");
+    g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : GT_SPMV_PB;
+    if (g->spmv_variant == GT_SPMV_PB) {
+        st = gt_pb_build(g);
+        if (st != GT_OK) { gt_graph_free(g); return st; }
+    }
     *out = g;
+    return GT_OK;
+}
+
+int gt_graph_select_spmv(gt_graph *g, int variant) {
+    GT_REQUIRE(g, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(variant == GT_SPMV_EDGE || variant == GT_SPMV_PB, GT_ERR_INVALID, "unknown SpMV variant %d", variant);
+    if (variant == GT_SPMV_PB && !g->pb) {
+        int st = gt_pb_build(g);
+        if (st != GT_OK) return st;
+    }
+    g->spmv_variant = variant;
     return GT_OK;
 }
 

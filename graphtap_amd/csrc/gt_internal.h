@@ -42,9 +42,17 @@ struct gt_graph {
     uint32_t *JV = nullptr;   // [H] local vertex -> compressed col
     uint32_t *R2C = nullptr;  // [nnzrows] compressed row -> compressed col of the same vertex, or ~0u
     uint32_t ncols_total = 0; // nranks * seg_stride
+    struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
+    int spmv_variant = 1;        // gt_spmv_variant
 };
+
+// pb.hip
+int gt_pb_build(gt_graph *g);
+void gt_pb_free(struct gt_pb *pb);
+int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
 // kernels.hip
+int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);

@@ -62,6 +62,11 @@ __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ 
 }  // namespace
 
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s) {
+    if (g->spmv_variant == GT_SPMV_PB) return gt_pb_spmv(g, semiring, x, y, s);
+    return gt_launch_spmv_edge(g, semiring, x, y, s);
+}
+
+int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s) {
     const uint64_t nnz = g->info.nnz_local;
     if (nnz == 0) return GT_OK;
     uint64_t blocks = ((nnz >> 2) + TPB - 1) / TPB;

@@ -56,6 +56,12 @@ typedef enum gt_semiring {
     GT_MINPLUS_U32 = 3   /* y[r] = min(y, x[c]+w)   SSSP,     sssp.h:48-51        */
 } gt_semiring;
 
+/* implementations of the generalized SpMV over a tile-row (same results, different HBM traffic) */
+typedef enum gt_spmv_variant {
+    GT_SPMV_EDGE = 0, /* one lane per stored entry, device atomics on y (correctness baseline)      */
+    GT_SPMV_PB = 1    /* propagation blocking: LDS-staged messages + LDS row-bin accumulators (default) */
+} gt_spmv_variant;
+
 typedef struct gt_graph gt_graph;     /* replaces Graph<> + Matrix<> + tile compressors */
 typedef struct gt_program gt_program; /* replaces Vertex_Program<>                       */
 
@@ -139,6 +145,9 @@ int gt_set_device(int device);
 int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
                    uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
+/* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
+ * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
+int gt_graph_select_spmv(gt_graph *g, int variant);
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
 /* Graph::free (mat/graph.hpp:76-81). Programs borrow the graph: free them first. */
 int gt_graph_free(gt_graph *g);
