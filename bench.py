@@ -168,7 +168,7 @@ def main():
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(i.nnzrows_global), "nnzcols": int(i.nnzcols_global),
                    "partition": "tile-rows x%d (1-D), all-gather of x per step" % world if world > 1 else "single tile",
                    "ingress_s": round(t_ingress, 3), "iterations_total": VR.iteration, "value_checksum": checksum[0], "reachable": checksum[1]},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv_edge<GT_PLUS_F64>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_pb_scatter<double> + k_pb_gather<double> (one SpMV launch pair)" if os.environ.get("GRAPHTAP_SPMV") != "edge" else "k_spmv_edge<GT_PLUS_F64>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
                      "kernel_ms": kernel_ms, "launches": launches},
     }

@@ -1,0 +1,197 @@
+// graphtap_amd.hpp -- header-only C++ shim over the C ABI (graphtap_amd.h) with the shape of the
+// reference's Graph<> / Vertex_Program<> so that application mains read like src/apps/*.cpp:
+//
+//     gt::Graph G;
+//     G.load(file_path, num_vertices, num_vertices, directed, transpose, self_loops, acyclic,
+//            parallel_edges, gt::_2DT_, gt::_TCSC_CF_);
+//     gt::Deg_Program V(G, stationary, gather_depends_on_apply, apply_depends_on_iter, gt::_COL_);
+//     V.execute(1);
+//     gt::PR_Program VR(G, stationary, gather_depends_on_apply, apply_depends_on_iter, gt::_ROW_);
+//     VR.initialize(V); V.free(); VR.execute(num_iterations); VR.checksum(); VR.display(); VR.free(); G.free();
+//
+// Differences from the reference that a caller sees:
+//  * the five programs are concrete classes; the virtual initializer/messenger/combiner/applicator
+//    hooks (src/vp/vertex_program.hpp:32-45) are device kernels selected by the class;
+//  * errors throw gt::Error instead of exit(1) (src/mat/graph.hpp:143-144);
+//  * weights are a run-time property of the Graph object (the reference uses -DHAS_WEIGHT);
+//  * V is struct-of-arrays copied out of HBM on demand (`V()`), not a std::vector of structs.
+#pragma once
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "graphtap_amd.h"
+
+namespace gt {
+
+enum Tiling_type { _2D_, _2DT_ };                          // src/mat/tiling.hpp:13-16
+enum Compression_type { _CSC_, _DCSC_, _TCSC_, _TCSC_CF_ };
+enum Ordering_type { _ROW_ = GT_ROW, _COL_ = GT_COL };     // src/vp/vertex_program.hpp:17-21
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+inline void check(int status) {
+    if (status != GT_OK) throw Error(std::string("graphtap_amd: ") + gt_last_error());
+}
+
+class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hpp:31-71
+  public:
+    explicit Graph(bool weighted = false) : weighted_(weighted) {}
+    ~Graph() {}  // like the reference: free() is explicit (graph.hpp:73-81)
+
+    void load(const std::string &filepath, uint32_t nrows, uint32_t ncols, bool directed = true, bool transpose = false,
+              bool self_loops = true, bool acyclic = false, bool parallel_edges = true, Tiling_type = _2DT_,
+              Compression_type compression_type = _CSC_) {
+        auto t0 = std::chrono::steady_clock::now();
+        if (nrows != ncols) throw Error("square matrices only");
+        if (compression_type != _TCSC_ && compression_type != _TCSC_CF_) throw Error("only TCSC / TCSC_CF tiles exist in this engine");
+        std::ifstream fin(filepath, std::ios::binary | std::ios::ate);
+        if (!fin.is_open()) throw Error("Unable to open input file");  // graph.hpp:311-314
+        const uint64_t bytes = (uint64_t)fin.tellg(), rec = weighted_ ? 12 : 8;
+        if (bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
+        std::vector<char> buf(bytes);
+        fin.seekg(0);
+        fin.read(buf.data(), (std::streamsize)bytes);
+        printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
+        load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+        printf("Ingress time: %f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    void load_edges(const void *edges, uint64_t m, uint32_t num_vertices, bool directed, bool transpose, bool self_loops,
+                    bool acyclic, bool parallel_edges, Compression_type compression_type, bool on_device = false) {
+        free();
+        gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
+        check(gt_graph_build(&h_, edges, m, on_device, weighted_, num_vertices, &f, 0, 1));
+        check(gt_graph_info_get(h_, &info));
+        compression = compression_type;
+    }
+    void free() {
+        if (h_) { check(gt_graph_free(h_)); h_ = nullptr; }
+    }
+    gt_graph *handle() const { return h_; }
+    gt_graph_info info{};
+    Compression_type compression = _TCSC_;
+
+  private:
+    bool weighted_;
+    gt_graph *h_ = nullptr;
+};
+
+class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
+  public:
+    Vertex_Program(Graph &G, int kind, bool stationary_, bool gather_depends_on_apply_, bool apply_depends_on_iter_, Ordering_type ot)
+        : stationary(stationary_), gather_depends_on_apply(gather_depends_on_apply_), apply_depends_on_iter(apply_depends_on_iter_),
+          G_(G), kind_(kind), order_(ot) {}
+    virtual ~Vertex_Program() {}
+
+    void initialize() { check(gt_program_initialize(handle())); already_initialized_ = true; }
+    void initialize(Vertex_Program &other) { check(gt_program_initialize_from(handle(), other.handle())); already_initialized_ = true; }
+    void execute(uint32_t num_iterations_ = 0) {  // vp:408-441
+        num_iterations = num_iterations_;
+        if (!already_initialized_) initialize();
+        check(gt_program_execute(handle(), num_iterations, &stats));
+        iteration = stats.iterations;
+        for (uint32_t i = 1; i <= iteration; i++) printf("Iteration:  %u\n", i);  // vp:422
+        printf("Execute time: %f seconds\n", stats.seconds);                       // vp:437
+    }
+    void checksum() {  // vp:1927-1960
+        uint64_t s = 0, c = 0;
+        check(gt_program_checksum(handle(), &s, &c));
+        printf("Iterations: %u\nValue checksum: %llu\nReachable vertices: %llu\n", iteration, (unsigned long long)s, (unsigned long long)c);
+    }
+    virtual std::string print_state(uint32_t i) = 0;
+    void display(uint32_t count = 31) {  // vp:2124-2181
+        count = count < G_.info.tile_height ? count : G_.info.tile_height;
+        fetch(count);
+        for (uint32_t i = 0; i < count; i++) printf("vertex[%u]:%s\n", i, print_state(i).c_str());
+    }
+    void free() {
+        if (h_) { check(gt_program_free(h_)); h_ = nullptr; }
+    }
+    gt_program *handle() {
+        if (!h_) {
+            gt_program_params p{kind_, order_, G_.compression == _TCSC_CF_ ? GT_TCSC_CF : GT_TCSC, root, alpha, tol};
+            check(gt_program_create(&h_, G_.handle(), &p));
+        }
+        return h_;
+    }
+    std::vector<uint32_t> state_u32(int field, uint32_t count) {
+        std::vector<uint32_t> v(count);
+        check(gt_program_copy_state(handle(), field, v.data(), count));
+        return v;
+    }
+    std::vector<double> state_f64(int field, uint32_t count) {
+        std::vector<double> v(count);
+        check(gt_program_copy_state(handle(), field, v.data(), count));
+        return v;
+    }
+
+    uint32_t num_iterations = 0, iteration = 0, root = 0;
+    bool stationary, gather_depends_on_apply, apply_depends_on_iter;
+    double alpha = 0.15, tol = 1e-5;  // pr.h:12-13
+    gt_exec_stats stats{};
+
+  protected:
+    virtual void fetch(uint32_t count) = 0;
+    Graph &G_;
+    int kind_;
+    Ordering_type order_;
+    gt_program *h_ = nullptr;
+    bool already_initialized_ = false;
+};
+
+static inline std::string inf_str(uint32_t v) { return v == GT_INF ? "INF" : std::to_string(v); }
+
+#define GT_PROGRAM(NAME, KIND)                                                                                          \
+    NAME(Graph &G, bool stationary_ = false, bool gather_depends_on_apply_ = false, bool apply_depends_on_iter_ = false, \
+         Ordering_type ot = _ROW_)                                                                                       \
+        : Vertex_Program(G, KIND, stationary_, gather_depends_on_apply_, apply_depends_on_iter_, ot) {}
+
+class Deg_Program : public Vertex_Program {  // src/apps/deg.h:27-53
+  public:
+    GT_PROGRAM(Deg_Program, GT_DEG)
+    std::vector<uint32_t> degree;
+    std::string print_state(uint32_t i) override { return "Degree=" + std::to_string(degree[i]); }
+  protected:
+    void fetch(uint32_t n) override { degree = state_u32(GT_F_DEGREE, n); }
+};
+class PR_Program : public Vertex_Program {  // src/apps/pr.h:21-48
+  public:
+    GT_PROGRAM(PR_Program, GT_PR)
+    std::vector<uint32_t> degree;
+    std::vector<double> rank;
+    std::string print_state(uint32_t i) override { return "Rank=" + std::to_string(rank[i]) + ",Degree=" + std::to_string(degree[i]); }
+  protected:
+    void fetch(uint32_t n) override { degree = state_u32(GT_F_DEGREE, n); rank = state_f64(GT_F_RANK, n); }
+};
+class BFS_Program : public Vertex_Program {  // src/apps/bfs.h:33-82
+  public:
+    GT_PROGRAM(BFS_Program, GT_BFS)
+    std::vector<uint32_t> parent, hops;
+    std::string print_state(uint32_t i) override { return "Parent=" + std::to_string(parent[i]) + ",Hops=" + inf_str(hops[i]); }
+  protected:
+    void fetch(uint32_t n) override { parent = state_u32(GT_F_PARENT, n); hops = state_u32(GT_F_HOPS, n); }
+};
+class SSSP_Program : public Vertex_Program {  // src/apps/sssp.h:29-71
+  public:
+    GT_PROGRAM(SSSP_Program, GT_SSSP)
+    std::vector<uint32_t> distance;
+    std::string print_state(uint32_t i) override { return "Distance=" + inf_str(distance[i]); }
+  protected:
+    void fetch(uint32_t n) override { distance = state_u32(GT_F_DISTANCE, n); }
+};
+class CC_Program : public Vertex_Program {  // src/apps/cc.h:29-60
+  public:
+    GT_PROGRAM(CC_Program, GT_CC)
+    std::vector<uint32_t> label;
+    std::string print_state(uint32_t i) override { return "Label=" + std::to_string(label[i]); }
+  protected:
+    void fetch(uint32_t n) override { label = state_u32(GT_F_LABEL, n); }
+};
+#undef GT_PROGRAM
+
+}  // namespace gt
