@@ -70,8 +70,11 @@ def main():
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb"),
+                    help="SpMV implementation (gt_spmv_variant): propagation blocking (default), the same with f32 messages, or the edge-atomic baseline")
     args = ap.parse_args()
 
+    os.environ["GRAPHTAP_SPMV"] = args.spmv
     import torch
     import torch.distributed as dist
     import graphtap_amd as gt
@@ -163,12 +166,14 @@ def main():
     out = {
         "metric": "PageRank GTEPS on RMAT-%d" % scale, "value": value, "unit": "GTEPS", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(i.nnzrows_global), "nnzcols": int(i.nnzcols_global),
-                   "partition": "tile-rows x%d (1-D), all-gather of x per step" % world if world > 1 else "single tile",
+                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), all-gather of x per step" % world if world > 1 else "single tile",
                    "ingress_s": round(t_ingress, 3), "iterations_total": VR.iteration, "value_checksum": checksum[0], "reachable": checksum[1]},
-        "roofline": {"bound": "hbm", "kernel": "k_pb_scatter<double> + k_pb_gather<double> (one SpMV launch pair)" if os.environ.get("GRAPHTAP_SPMV") != "edge" else "k_spmv_edge<GT_PLUS_F64>", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter<double,double> + k_pb_gather<double,double> (one SpMV = this launch pair)",
+                                                  "pb_f32msg": "k_pb_scatter<double,float> + k_pb_gather<double,float> (one SpMV = this launch pair)",
+                                                  "edge": "k_spmv_edge<GT_PLUS_F64>"}[args.spmv], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
                      "kernel_ms": kernel_ms, "launches": launches},
     }

@@ -11,7 +11,7 @@ GT_DEG, GT_PR, GT_BFS, GT_SSSP, GT_CC = range(5)
 GT_ROW, GT_COL = 0, 1
 GT_TCSC, GT_TCSC_CF = 0, 1
 GT_PLUS_F64, GT_PLUS_U32, GT_MIN_U32, GT_MINPLUS_U32 = range(4)
-GT_SPMV_EDGE, GT_SPMV_PB = 0, 1
+GT_SPMV_EDGE, GT_SPMV_PB, GT_SPMV_PB_F32MSG = 0, 1, 2
 GT_F_DEGREE, GT_F_RANK, GT_F_PARENT, GT_F_HOPS, GT_F_DISTANCE, GT_F_LABEL, GT_F_ACTIVE = range(7)
 
 

@@ -271,8 +271,8 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_graph_free(g); return st; }
     const char *env = getenv("GRAPHTAP_SPMV");
-    g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : GT_SPMV_PB;
-    if (g->spmv_variant == GT_SPMV_PB) {
+    g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : (env && strcmp(env, "pb_f32msg") == 0) ? GT_SPMV_PB_F32MSG : GT_SPMV_PB;
+    if (g->spmv_variant != GT_SPMV_EDGE) {
         st = gt_pb_build(g);
         if (st != GT_OK) { gt_graph_free(g); return st; }
     }
@@ -282,8 +282,8 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
 
 int gt_graph_select_spmv(gt_graph *g, int variant) {
     GT_REQUIRE(g, GT_ERR_INVALID, "null argument");
-    GT_REQUIRE(variant == GT_SPMV_EDGE || variant == GT_SPMV_PB, GT_ERR_INVALID, "unknown SpMV variant %d", variant);
-    if (variant == GT_SPMV_PB && !g->pb) {
+    GT_REQUIRE(variant >= GT_SPMV_EDGE && variant <= GT_SPMV_PB_F32MSG, GT_ERR_INVALID, "unknown SpMV variant %d", variant);
+    if (variant != GT_SPMV_EDGE && !g->pb) {
         int st = gt_pb_build(g);
         if (st != GT_OK) return st;
     }

@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ 
 }  // namespace
 
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s) {
-    if (g->spmv_variant == GT_SPMV_PB) return gt_pb_spmv(g, semiring, x, y, s);
+    if (g->spmv_variant == GT_SPMV_PB) return gt_pb_spmv(g, semiring, x, y, s, false);
+    if (g->spmv_variant == GT_SPMV_PB_F32MSG) return gt_pb_spmv(g, semiring, x, y, s, true);
     return gt_launch_spmv_edge(g, semiring, x, y, s);
 }
 

@@ -22,13 +22,15 @@
 //                 bit 15: first entry of a (chunk, bin) segment
 //   LROW[k]  u16  k-order = segments sorted by (bin, chunk); row & (R-1)
 //   WT[v]    u32  weights in v-order (min-plus only)
-//   KSTART[s], GS[g], GO[g]: where segment s starts in k-order; for every group of 64 entries the
-//                 segment its first entry belongs to and the offset into it.
+//   KSTART[s], G[g]: where segment s starts in k-order; for every group of 64 entries of the
+//                 v-order the k-slot of its first entry and of its first segment head.
 // HBM traffic per entry per SpMV: 2 + F (phase 1) + F + 2 (phase 2) + ~0.2 -> 20.2 B for f64,
 // 12.2 B for u32, against the 4.6 / 4.4 B of the algorithmic minimum.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "gt_internal.h"
@@ -40,7 +42,7 @@ constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulator
 constexpr uint32_t W = 8192;           // columns per window: 64 KiB of f64 messages in LDS
 constexpr uint32_t CH_DEFAULT = 1u << 18;
 constexpr uint32_t EPW = 1u << 18;     // entries per phase-2 workgroup
-constexpr int P1_THREADS = 512;
+constexpr int P1_THREADS = 1024;
 constexpr int P2_THREADS = 1024;
 constexpr uint16_t HEAD = 0x8000;
 constexpr int TPB = 256;
@@ -89,6 +91,18 @@ __global__ void k_keys(const uint32_t *__restrict__ cv0, const uint32_t *__restr
         idx[e] = (uint32_t)e;
     }
 }
+__global__ void k_chunk_row_keys(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1, const uint32_t *__restrict__ IA,
+                                 uint64_t *__restrict__ key) {
+    const uint32_t c = blockIdx.x;
+    for (uint64_t e = (uint64_t)cv0[c] + threadIdx.x; e < cv1[c]; e += blockDim.x) key[e] = ((uint64_t)c << 32) | IA[e];
+}
+__global__ void k_count_unique64(const uint64_t *__restrict__ key, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        c += (i == 0 || key[i] != key[i - 1]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 __global__ void k_iota(uint32_t *__restrict__ p, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
@@ -125,7 +139,7 @@ __global__ void k_static_streams(const uint32_t *__restrict__ key, const uint32_
                                  uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ IA,
                                  const uint32_t *__restrict__ JI, const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart,
                                  const uint32_t *__restrict__ kstart, uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW,
-                                 uint32_t *__restrict__ WT, uint32_t *__restrict__ GS, uint32_t *__restrict__ GO) {
+                                 uint32_t *__restrict__ WT) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t e = idx[v], c = key[v] >> binbits, s = sid[v] - 1;
         bool head = (v == 0 || key[v] != key[v - 1]);
@@ -133,85 +147,133 @@ __global__ void k_static_streams(const uint32_t *__restrict__ key, const uint32_
         uint32_t k = kstart[s] + ((uint32_t)v - vstart[s]);
         LROW[k] = (uint16_t)(IA[e] & (R - 1));
         if (WT) WT[v] = A[e];
-        if ((v & 63) == 0) { GS[v >> 6] = s; GO[v >> 6] = (uint32_t)v - vstart[s]; }
+    }
+}
+// Group table: for every 64 consecutive entries of the v-order, where lane 0 lands in the k-order
+// (k0), where the first six segment heads among lanes 1..63 land (k[0..5]) and the segment of lane 0
+// (s, for the rare groups with seven or more heads). One 32-byte scalar load per group in phase 1,
+// so that no load of phase 1 depends on another load.
+struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes: one s_load_dwordx8 per group
+__global__ void k_group_table(const uint32_t *__restrict__ key, const uint32_t *__restrict__ sid, uint64_t n, uint32_t nseg,
+                              const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ kstart, GroupRec *__restrict__ G) {
+    const uint64_t ngroups = (n + 63) / 64;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = g * 64;
+        const uint32_t s0 = sid[v] - 1;
+        GroupRec r;
+        r.s = s0; r.k0 = kstart[s0] + ((uint32_t)v - vstart[s0]);
+        // segments are numbered in v-order: the i-th head among lanes 1..63 opens segment s0 + i
+        for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nseg) ? kstart[s0 + 1 + i] : 0;
+        G[g] = r;
     }
 }
 
 // ------------------------------------------------------------------ phase 1
-template <class T> struct Msg;
-template <> struct Msg<double> { static __device__ __forceinline__ double val(double x, uint32_t) { return x; } };
-template <> struct Msg<uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
+// T  = type of x / y / the LDS accumulators (double or uint32_t)
+// TV = type of the value stream VAL and of the LDS message window: T, or float for the
+//      "f32 messages" PageRank variant (messages rounded to f32, sums still accumulated in f64)
+template <class T, class TV> struct Msg;
+template <> struct Msg<double, double> { static __device__ __forceinline__ double val(double x, uint32_t) { return x; } };
+template <> struct Msg<double, float> { static __device__ __forceinline__ float val(float x, uint32_t) { return x; } };
+template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
 
-template <class T, bool WEIGHTED>
+template <class T, class TV, bool WEIGHTED>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nnz,
                                                            const uint16_t *__restrict__ LCOL, const uint32_t *__restrict__ WT,
-                                                           const uint32_t *__restrict__ KSTART, const uint32_t *__restrict__ GS,
-                                                           const uint32_t *__restrict__ GO, const T *__restrict__ x, T *__restrict__ VAL) {
-    __shared__ T xwin[W];
+                                                           const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
+                                                           const T *__restrict__ x, TV *__restrict__ VAL) {
+    __shared__ TV xwin[W];
     const uint32_t c = blockIdx.x;
     const uint32_t v0 = cv0[c], v1 = cv1[c], col0 = ccol0[c];
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
-    for (uint32_t i = threadIdx.x; i < wn; i += P1_THREADS) xwin[i] = x[col0 + i];
+    {   // stage the window: all loads of a lane in flight together
+        constexpr int PER = W / P1_THREADS;
+        T t[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; t[i] = (j < wn) ? x[col0 + j] : T(0); }
+#pragma unroll
+        for (int i = 0; i < PER; i++) xwin[threadIdx.x + i * P1_THREADS] = (TV)t[i];
+    }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t NW = P1_THREADS / 64;
+    constexpr int U = 8;   // 64-entry groups in flight per wave
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes 0..lane
-    // groups of 64 entries aligned to 64 in v-space; a group at a chunk border is visited by both chunks
-    for (uint32_t g = (v0 >> 6) + wave; (uint64_t)g * 64 < v1; g += NW) {
-        const uint64_t v = (uint64_t)g * 64 + lane;
-        uint16_t lc = (v < nnz) ? LCOL[v] : (uint16_t)0;
-        const uint64_t heads = __ballot((lc & HEAD) != 0) & lane_le & ~1ull;  // heads in lanes 1..lane
-        const uint32_t gs = GS[g], go = GO[g];
-        uint32_t k;
-        if (heads == 0) {
-            k = KSTART[gs] + go + lane;
-        } else {
-            const uint32_t cnt = __popcll(heads), hpos = 63 - __clzll(heads);
-            k = KSTART[gs + cnt] + (lane - hpos);
+    const uint32_t gend = (uint32_t)(((uint64_t)v1 + 63) >> 6);
+    const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
+    // Groups of 64 entries are aligned to 64 in v-space; a group at a chunk border is visited by both
+    // chunks, each storing only its own lanes. Software pipeline: the loads of trip t+1 are issued
+    // BEFORE the stores of trip t, so a wave does not wait on its own store acknowledgements (vmcnt
+    // retires in order) to see its next inputs.
+    uint16_t lc[U], nlc[U]; uint32_t gw[U], ngw[U], w[U], nw[U];
+    auto issue_loads = [&](uint32_t g0, uint16_t (&olc)[U], uint32_t (&ogw)[U], uint32_t (&ow)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
+            const uint64_t v = (uint64_t)g * 64 + lane;
+            olc[u] = (v < nnz) ? LCOL[v] : (uint16_t)0;                // 2 B/lane
+            ogw[u] = Gw[(uint64_t)g * 8 + (lane & 7)];                  // lane i holds dword i & 7 of the 32-byte group record
+            if constexpr (WEIGHTED) ow[u] = (v >= v0 && v < v1) ? WT[v] : 0u; else ow[u] = 0;
         }
-        if (v >= v0 && v < v1) {
-            uint32_t w = 0;
-            if constexpr (WEIGHTED) w = WT[v];
-            VAL[k] = Msg<T>::val(xwin[lc & (W - 1)], w);
+    };
+    uint32_t g0 = (v0 >> 6) + wave * U;
+    if (g0 < gend) issue_loads(g0, lc, gw, w);
+    while (g0 < gend) {
+        const uint32_t gn = g0 + NW * U;
+        if (gn < gend) issue_loads(gn, nlc, ngw, nw);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t g = g0 + u;
+            if (g >= gend) break;
+            const uint64_t v = (uint64_t)g * 64 + lane;
+            const uint64_t heads = __ballot((lc[u] & HEAD) != 0) & lane_le & ~1ull;  // heads in lanes 1..lane
+            const uint32_t cnt = __popcll(heads);
+            const uint32_t hpos = heads ? 63 - __clzll(heads) : 0;
+            // dword 0 = k of lane 0; dword i (1..6) = k of the i-th head; dword 7 = segment of lane 0
+            const uint32_t ks = __shfl(gw[u], cnt < 7 ? cnt : 7);
+            const bool mine = (v >= v0 && v < v1);
+            const bool rare = (cnt >= 7);   // seven or more runs inside 64 entries: < 1 % of the entries
+            const TV val = Msg<T, TV>::val(xwin[lc[u] & (W - 1)], w[u]);
+            if (__ballot(rare) != 0) {      // wave-uniform branch: the dependent load and its wait stay in here
+                if (rare && mine) VAL[KSTART[ks + cnt] + (lane - hpos)] = val;
+            }
+            if (!rare && mine) VAL[ks + (lane - hpos)] = val;
         }
+        g0 = gn;
+#pragma unroll
+        for (int u = 0; u < U; u++) { lc[u] = nlc[u]; gw[u] = ngw[u]; w[u] = nw[u]; }
     }
 }
 
 // ------------------------------------------------------------------ phase 2
 struct BinWork { uint32_t bin, k0, k1, single; };
 
-template <class T, bool IS_MIN>
+template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *acc, uint32_t r, T a) {
+    if constexpr (IS_MIN) { if (a != GT_INF) atomicMin(&acc[r], a); }
+    else if constexpr (sizeof(T) == 8) unsafeAtomicAdd(&acc[r], a);   // ds_add_f64
+    else atomicAdd(&acc[r], a);
+}
+
+template <class T, class TV, bool IS_MIN>
 __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restrict__ work, const uint16_t *__restrict__ LROW,
-                                                          const T *__restrict__ VAL, uint32_t nrows, T *__restrict__ y) {
+                                                          const TV *__restrict__ VAL, uint32_t nrows, T *__restrict__ y) {
     __shared__ T acc[R];
     const BinWork wk = work[blockIdx.x];
     const T neutral = IS_MIN ? (T)GT_INF : (T)0;
     for (uint32_t i = threadIdx.x; i < R; i += P2_THREADS) acc[i] = neutral;
     __syncthreads();
-    // 4 entries per lane per trip, issued before the first LDS atomic
+    // 4 entries per lane per trip, all loads issued before the first LDS atomic
     uint64_t k = (uint64_t)wk.k0 + threadIdx.x;
     const uint64_t k1 = wk.k1;
     for (; k + 3ull * P2_THREADS < k1; k += 4ull * P2_THREADS) {
         uint16_t r0 = LROW[k], r1 = LROW[k + P2_THREADS], r2 = LROW[k + 2 * P2_THREADS], r3 = LROW[k + 3 * P2_THREADS];
-        T a0 = VAL[k], a1 = VAL[k + P2_THREADS], a2 = VAL[k + 2 * P2_THREADS], a3 = VAL[k + 3 * P2_THREADS];
-        if constexpr (IS_MIN) {
-            if (a0 != GT_INF) atomicMin(&acc[r0], a0);
-            if (a1 != GT_INF) atomicMin(&acc[r1], a1);
-            if (a2 != GT_INF) atomicMin(&acc[r2], a2);
-            if (a3 != GT_INF) atomicMin(&acc[r3], a3);
-        } else if constexpr (sizeof(T) == 8) {
-            unsafeAtomicAdd(&acc[r0], a0); unsafeAtomicAdd(&acc[r1], a1); unsafeAtomicAdd(&acc[r2], a2); unsafeAtomicAdd(&acc[r3], a3);
-        } else {
-            atomicAdd(&acc[r0], a0); atomicAdd(&acc[r1], a1); atomicAdd(&acc[r2], a2); atomicAdd(&acc[r3], a3);
-        }
+        TV a0 = VAL[k], a1 = VAL[k + P2_THREADS], a2 = VAL[k + 2 * P2_THREADS], a3 = VAL[k + 3 * P2_THREADS];
+        lds_combine<T, IS_MIN>(acc, r0, (T)a0); lds_combine<T, IS_MIN>(acc, r1, (T)a1);
+        lds_combine<T, IS_MIN>(acc, r2, (T)a2); lds_combine<T, IS_MIN>(acc, r3, (T)a3);
     }
-    for (; k < k1; k += P2_THREADS) {
-        uint16_t r0 = LROW[k]; T a0 = VAL[k];
-        if constexpr (IS_MIN) { if (a0 != GT_INF) atomicMin(&acc[r0], a0); }
-        else if constexpr (sizeof(T) == 8) unsafeAtomicAdd(&acc[r0], a0);
-        else atomicAdd(&acc[r0], a0);
-    }
+    for (; k < k1; k += P2_THREADS) lds_combine<T, IS_MIN>(acc, LROW[k], (T)VAL[k]);
     __syncthreads();
     const uint32_t row0 = wk.bin << RB;
     const uint32_t rn = (nrows - row0 < R) ? nrows - row0 : R;
@@ -235,7 +297,8 @@ struct gt_pb {
     uint32_t nbins = 0, nchunks = 0, nwork = 0, nnz = 0;
     uint32_t *cv0 = nullptr, *cv1 = nullptr, *ccol0 = nullptr;
     uint16_t *LCOL = nullptr, *LROW = nullptr;
-    uint32_t *WT = nullptr, *KSTART = nullptr, *GS = nullptr, *GO = nullptr;
+    uint32_t *WT = nullptr, *KSTART = nullptr;
+    void *G = nullptr;  // GroupRec per 64 entries
     BinWork *work = nullptr;
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
@@ -243,7 +306,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->GS, pb->GO, pb->work, pb->VAL};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -342,6 +405,27 @@ int gt_pb_build(gt_graph *g) {
         DevBuf st; PB_ALLOC(st, tb);
         PB_HIP(hipcub::DeviceScan::ExclusiveSum(st.p, tb, lens.as<uint32_t>(), kscan.as<uint32_t>(), nseg, s));
     }
+    if (getenv("GRAPHTAP_PB_STATS")) {  // how many (chunk, row) pairs are distinct? (what pre-aggregation in phase 1 would leave)
+        DevBuf k64, k64b; PB_ALLOC(k64, (uint64_t)nnz * 8); PB_ALLOC(k64b, (uint64_t)nnz * 8);
+        k_chunk_row_keys<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, g->IA, k64.as<uint64_t>());
+        hipcub::DoubleBuffer<uint64_t> d64(k64.as<uint64_t>(), k64b.as<uint64_t>());
+        size_t tb = 0;
+        PB_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d64, nnz, 0, 32 + chunkbits, s));
+        DevBuf st; PB_ALLOC(st, tb);
+        PB_HIP(hipcub::DeviceRadixSort::SortKeys(st.p, tb, d64, nnz, 0, 32 + chunkbits, s));
+        DevBuf cntb; PB_ALLOC(cntb, 8); PB_HIP(hipMemsetAsync(cntb.p, 0, 8, s));
+        k_count_unique64<<<grid_for(nnz), TPB, 0, s>>>(d64.Current(), nnz, cntb.as<unsigned long long>());
+        unsigned long long uq = 0; PB_HIP(hipMemcpy(&uq, cntb.p, 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pb] distinct (chunk,row) pairs: %llu of %u entries -> pre-aggregation factor %.3f\n", uq, nnz, (double)nnz / uq);
+    }
+    if (getenv("GRAPHTAP_PB_STATS")) {  // entry-weighted histogram of (chunk, bin) run lengths
+        std::vector<uint32_t> hl(nseg);
+        PB_HIP(hipMemcpy(hl.data(), lens.p, (uint64_t)nseg * 4, hipMemcpyDeviceToHost));
+        uint64_t hist[33] = {0}, cnt[33] = {0};
+        for (uint32_t l : hl) { int b = 0; while ((1u << (b + 1)) <= l) b++; hist[b] += l; cnt[b]++; }
+        fprintf(stderr, "[pb] nnz=%u nbins=%u nchunks=%u nseg=%u mean run=%.1f\n", nnz, pb->nbins, nchunks, nseg, (double)nnz / nseg);
+        for (int b = 0; b < 33; b++) if (cnt[b]) fprintf(stderr, "[pb] run length [%u,%u): %10llu runs, %5.2f%% of entries\n", 1u << b, 1u << (b + 1), (unsigned long long)cnt[b], 100.0 * hist[b] / nnz);
+    }
     PB_MALLOC(pb->KSTART, (uint64_t)(nseg + 64) * 4);
     PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nseg + 64) * 4, s));
     k_kstart<<<grid_for(nseg), TPB, 0, s>>>(order.as<uint32_t>(), kscan.as<uint32_t>(), nseg, pb->KSTART);
@@ -350,10 +434,11 @@ int gt_pb_build(gt_graph *g) {
 
     const uint64_t ngroups = ((uint64_t)nnz + 63) / 64;
     PB_MALLOC(pb->LCOL, (uint64_t)nnz * 2); PB_MALLOC(pb->LROW, (uint64_t)nnz * 2);
-    PB_MALLOC(pb->GS, ngroups * 4); PB_MALLOC(pb->GO, ngroups * 4);
+    PB_MALLOC(pb->G, ngroups * sizeof(GroupRec));
     if (g->A) PB_MALLOC(pb->WT, (uint64_t)nnz * 4);
     k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey, sidx, sid, nnz, binbits, pb->ccol0, g->IA, g->JI, g->A, vstart.as<uint32_t>(),
-                                                   pb->KSTART, pb->LCOL, pb->LROW, pb->WT, pb->GS, pb->GO);
+                                                   pb->KSTART, pb->LCOL, pb->LROW, pb->WT);
+    k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(skey, sid, nnz, nseg, vstart.as<uint32_t>(), pb->KSTART, (GroupRec *)pb->G);
     // phase-2 work list (host: nbins is small)
     std::vector<uint32_t> hoff(pb->nbins + 1);
     PB_HIP(hipMemcpyAsync(hoff.data(), binoff.p, (uint64_t)(pb->nbins + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -377,20 +462,20 @@ int gt_pb_build(gt_graph *g) {
     return GT_OK;
 }
 
-template <class T, bool WEIGHTED, bool IS_MIN>
+template <class T, class TV, bool WEIGHTED, bool IS_MIN>
 static int pb_run(const gt_graph *g, gt_pb *pb, const T *x, T *y, hipStream_t s) {
-    k_pb_scatter<T, WEIGHTED><<<pb->nchunks, P1_THREADS, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->nnz, pb->LCOL, pb->WT,
-                                                                 pb->KSTART, pb->GS, pb->GO, x, (T *)pb->VAL);
-    k_pb_gather<T, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, pb->LROW, (const T *)pb->VAL, g->info.nnzrows, y);
+    k_pb_scatter<T, TV, WEIGHTED><<<pb->nchunks, P1_THREADS, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->nnz, pb->LCOL, pb->WT,
+                                                                     pb->KSTART, (const GroupRec *)pb->G, x, (TV *)pb->VAL);
+    k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, pb->LROW, (const TV *)pb->VAL, g->info.nnzrows, y);
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
-int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s) {
+int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
-    const uint32_t need = (semiring == GT_PLUS_F64) ? 8 : 4;
+    const uint32_t need = (semiring == GT_PLUS_F64 && !f32_messages) ? 8 : 4;
     if (pb->val_bytes < need) {  // one value stream per graph: SpMVs of one graph must not overlap in time
         if (pb->VAL) GT_HIP(hipFree(pb->VAL));
         pb->VAL = nullptr; pb->val_bytes = 0;
@@ -398,12 +483,14 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
         pb->val_bytes = need;
     }
     switch (semiring) {
-        case GT_PLUS_F64: return pb_run<double, false, false>(g, pb, (const double *)x, (double *)y, s);
-        case GT_PLUS_U32: return pb_run<uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
-        case GT_MIN_U32: return pb_run<uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+        case GT_PLUS_F64:
+            if (f32_messages) return pb_run<double, float, false, false>(g, pb, (const double *)x, (double *)y, s);
+            return pb_run<double, double, false, false>(g, pb, (const double *)x, (double *)y, s);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+            return pb_run<uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

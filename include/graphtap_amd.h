@@ -59,7 +59,9 @@ typedef enum gt_semiring {
 /* implementations of the generalized SpMV over a tile-row (same results, different HBM traffic) */
 typedef enum gt_spmv_variant {
     GT_SPMV_EDGE = 0, /* one lane per stored entry, device atomics on y (correctness baseline)      */
-    GT_SPMV_PB = 1    /* propagation blocking: LDS-staged messages + LDS row-bin accumulators (default) */
+    GT_SPMV_PB = 1,   /* propagation blocking: LDS-staged messages + LDS row-bin accumulators (default) */
+    GT_SPMV_PB_F32MSG = 2 /* same, PageRank messages rounded to f32 in flight (sums, ranks and y stay f64);
+                             halves the value stream; integer semirings are unaffected */
 } gt_spmv_variant;
 
 typedef struct gt_graph gt_graph;     /* replaces Graph<> + Matrix<> + tile compressors */

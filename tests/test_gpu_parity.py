@@ -434,3 +434,21 @@ def test_propagation_blocking_equals_edge_kernel(gt, scale, nranks, rank):
     a, b = run(G, gt._lib.GT_PLUS_U32, (xi & 0xFF).astype(np.uint32), (yi & 0xFFFF).astype(np.uint32))
     assert (a == b).all()
     G.free()
+
+
+@pytest.mark.parametrize("scale,seed", [(12, 2), (16, 1), (18, 2), (20, 3)])
+def test_pagerank_f32_message_variant_within_tolerance(gt, O, scale, seed, monkeypatch):
+    """GT_SPMV_PB_F32MSG rounds the PageRank messages x = rank/degree to f32 in flight (sums, y and ranks
+    stay f64). The north-star tolerance for PageRank is 1e-6 relative against the fp64 reference; this pins
+    the variant to it on the same seeded inputs as the f64 path, 20 iterations."""
+    from graphtap_amd.rmat import rmat_edges
+    nv = 1 << scale
+    e = rmat_edges(scale, 16, seed)
+    ref = O.run_app("pr", e, nv, iters=20)
+    monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    r = run_pr(gt, e, nv, 20)
+    monkeypatch.delenv("GRAPHTAP_SPMV")
+    assert (r["degree"] == ref["degree"]).all()
+    rel = np.abs(r["rank"] - ref["rank"]) / ref["rank"]
+    print("f32-message PageRank scale %d: max rel err %.3g" % (scale, rel.max()))
+    assert rel.max() < PR_RTOL
