@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
     ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb"),
                     help="SpMV implementation (gt_spmv_variant): propagation blocking (default), the same with f32 messages, or the edge-atomic baseline")
     args = ap.parse_args()
@@ -87,11 +88,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     _lib.require_gpu()
+    if os.environ.get("GRAPHTAP_SHARE_GPU"):   # rehearsal of the N-rank path on a 1-GPU box: all ranks on device 0
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     _lib.check(L.gt_set_device(local))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,10 +150,9 @@ def main():
     if world == 1:
         b_alg = 4 * i.nnz_local + 4 * (i.nnzcols + 1) + F * i.nnzcols + F * i.nnzrows
     kernel_ms = spmv_ms / launches
-    t = torch.tensor([dt, kernel_ms, float(b_alg)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, kernel_ms, float(b_alg)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
-        dist.all_reduce(t[:2], op=dist.ReduceOp.MAX)
-        tb = t[2:].clone(); dist.all_reduce(tb, op=dist.ReduceOp.MAX); t[2] = tb[0]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, kernel_ms, b_alg = float(t[0]), float(t[1]), float(t[2])
     nnz = G.nnz_global
     value = nnz * args.steps / dt / 1e9

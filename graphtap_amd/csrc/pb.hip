@@ -264,16 +264,35 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     const T neutral = IS_MIN ? (T)GT_INF : (T)0;
     for (uint32_t i = threadIdx.x; i < R; i += P2_THREADS) acc[i] = neutral;
     __syncthreads();
-    // 4 entries per lane per trip, all loads issued before the first LDS atomic
-    uint64_t k = (uint64_t)wk.k0 + threadIdx.x;
-    const uint64_t k1 = wk.k1;
-    for (; k + 3ull * P2_THREADS < k1; k += 4ull * P2_THREADS) {
-        uint16_t r0 = LROW[k], r1 = LROW[k + P2_THREADS], r2 = LROW[k + 2 * P2_THREADS], r3 = LROW[k + 3 * P2_THREADS];
-        TV a0 = VAL[k], a1 = VAL[k + P2_THREADS], a2 = VAL[k + 2 * P2_THREADS], a3 = VAL[k + 3 * P2_THREADS];
-        lds_combine<T, IS_MIN>(acc, r0, (T)a0); lds_combine<T, IS_MIN>(acc, r1, (T)a1);
-        lds_combine<T, IS_MIN>(acc, r2, (T)a2); lds_combine<T, IS_MIN>(acc, r3, (T)a3);
+    // Main loop: 4 consecutive entries per lane per load (16-byte VAL loads for f32/u32 streams, 2 x 16 B for
+    // f64; 8-byte LROW loads), two such quads in flight per lane; scalar head and tail around the 4-aligned body.
+    const uint64_t k0 = wk.k0, k1 = wk.k1;
+    const uint64_t ka = (k0 + 3) & ~3ull, kb = k1 & ~3ull;   // aligned body [ka, kb)
+    if (ka >= kb) {
+        for (uint64_t k = k0 + threadIdx.x; k < k1; k += P2_THREADS) lds_combine<T, IS_MIN>(acc, LROW[k], (T)VAL[k]);
+    } else {
+        if (k0 + threadIdx.x < ka) lds_combine<T, IS_MIN>(acc, LROW[k0 + threadIdx.x], (T)VAL[k0 + threadIdx.x]);
+        if (kb + threadIdx.x < k1) lds_combine<T, IS_MIN>(acc, LROW[kb + threadIdx.x], (T)VAL[kb + threadIdx.x]);
+        struct alignas(8) R4 { uint16_t r[4]; };
+        struct alignas(4 * sizeof(TV) > 16 ? 16 : 4 * sizeof(TV)) V4 { TV a[4]; };
+        const R4 *__restrict__ LR4 = reinterpret_cast<const R4 *>(LROW);
+        const V4 *__restrict__ VA4 = reinterpret_cast<const V4 *>(VAL);
+        const uint64_t qa = ka >> 2, qb = kb >> 2;
+        uint64_t q = qa + threadIdx.x;
+        for (; q + P2_THREADS < qb; q += 2ull * P2_THREADS) {
+            const R4 r0 = LR4[q], r1 = LR4[q + P2_THREADS];
+            const V4 a0 = VA4[q], a1 = VA4[q + P2_THREADS];
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.r[j], (T)a0.a[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r1.r[j], (T)a1.a[j]);
+        }
+        if (q < qb) {
+            const R4 r0 = LR4[q]; const V4 a0 = VA4[q];
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.r[j], (T)a0.a[j]);
+        }
     }
-    for (; k < k1; k += P2_THREADS) lds_combine<T, IS_MIN>(acc, LROW[k], (T)VAL[k]);
     __syncthreads();
     const uint32_t row0 = wk.bin << RB;
     const uint32_t rn = (nrows - row0 < R) ? nrows - row0 : R;

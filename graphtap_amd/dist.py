@@ -22,6 +22,28 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t):
+    """gloo cannot move device tensors for every collective: rehearsal runs of the N-rank path on a box
+    without RCCL peers stage through the host. The product path (backend nccl = RCCL) never does."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
+def all_gather_segments(x, mine, group=None):
+    if _staged(x):
+        h = x.cpu(); m = mine.cpu().clone()
+        dist.all_gather_into_tensor(h, m, group=group)
+        x.copy_(h)
+    else:
+        dist.all_gather_into_tensor(x, mine, group=group)
+
+
+def all_reduce_sum(t, group=None):
+    if _staged(t):
+        h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 def run(engine, iters, group=None):
     """Vertex_Program::execute (vp:408-441) across ranks. Returns (iterations, converged)."""
     check = (iters == 0)
@@ -32,15 +54,15 @@ def run(engine, iters, group=None):
     while True:
         engine.scatter_gather()
         if p > 1 and engine.needs_x_exchange:
-            dist.all_gather_into_tensor(x, mine, group=group)
+            all_gather_segments(x, mine, group=group)
         engine.combine()
         if p > 1 and engine.column_accumulators:
-            dist.all_reduce(engine.y_tensor(), group=group)
+            all_reduce_sum(engine.y_tensor(), group=group)
         active = engine.apply(iters, check)
         if check:
             if p > 1:
                 t = torch.tensor([active], dtype=torch.int64, device=x.device)
-                dist.all_reduce(t, group=group)
+                all_reduce_sum(t, group=group)
                 active = int(t.item())
             if active == 0:
                 engine.finish_converged()

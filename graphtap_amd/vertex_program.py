@@ -49,8 +49,19 @@ class _HipEngine:
         return torch.as_tensor(_CudaArray(ptr.value, n.value, "<f8" if w.value == 8 else "<i4"), device="cuda")
 
     def x_tensor(self):
+        """The message vector handed to the collective. For a multi-rank run it is a torch allocation
+        installed into the engine (gt_program_set_x), so RCCL sees ordinary caching-allocator memory;
+        the single-rank loopback tests view the engine's own buffer."""
         if self._x is None:
-            self._x = self._tensor(lib().gt_program_x)
+            if self.nranks > 1:
+                import torch
+                ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
+                check(lib().gt_program_x(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
+                own = torch.as_tensor(_CudaArray(ptr.value, n.value, "<f8" if w.value == 8 else "<i4"), device="cuda")
+                self._x = own.clone()            # keeps whatever initialize() put there
+                check(lib().gt_program_set_x(self.prog._h, C.c_void_p(self._x.data_ptr())))
+            else:
+                self._x = self._tensor(lib().gt_program_x)
         return self._x
 
     def y_tensor(self):
@@ -145,7 +156,9 @@ class Vertex_Program:
             import torch
             from . import dist as gdist
             check(lib().gt_program_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            _, self.converged = gdist.run(_HipEngine(self), self.num_iterations)
+            if getattr(self, "_engine", None) is None:
+                self._engine = _HipEngine(self)
+            _, self.converged = gdist.run(self._engine, self.num_iterations)
         return self
 
     # -- V, vp:61 (owned segment; struct-of-arrays)

@@ -47,6 +47,36 @@ __global__ void __launch_bounds__(1024) k_expand16(const uint16_t *__restrict__ 
         for (int u = 0; u < U; u++) if (i + u * stride < n) out[i + u * stride] = tab[v[u] & 8191];
     }
 }
+// f32 output, one entry per lane per access (2 B in, 4 B out) vs four entries per lane (8 B in, 16 B out)
+template <int U>
+__global__ void __launch_bounds__(1024) k_expand16_f32(const uint16_t *__restrict__ idx, float *__restrict__ out, uint64_t n) {
+    __shared__ float tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) tab[i] = i;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride * U) {
+        uint16_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (i + u * stride < n) ? idx[i + u * stride] : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) if (i + u * stride < n) out[i + u * stride] = tab[v[u] & 8191];
+    }
+}
+template <int U>
+__global__ void __launch_bounds__(1024) k_expand16x4_f32(const ushort4 *__restrict__ idx, float4 *__restrict__ out, uint64_t n4) {
+    __shared__ float tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) tab[i] = i;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n4; i += stride * U) {
+        ushort4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (i + u * stride < n4) ? idx[i + u * stride] : make_ushort4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; u++) if (i + u * stride < n4)
+            out[i + u * stride] = make_float4(tab[v[u].x & 8191], tab[v[u].y & 8191], tab[v[u].z & 8191], tab[v[u].w & 8191]);
+    }
+}
 // every wave writes runs of `run` doubles at pseudo-random run-aligned places (each place written once)
 __global__ void k_scatter_runs(double *__restrict__ a, uint64_t nruns, uint32_t run, uint64_t mul) {
     const uint32_t lane = threadIdx.x & 63;
@@ -80,6 +110,11 @@ int main() {
     timeit("expand u16->f64 via LDS, U=8 (r+w)", (bytes + bytes / 4) / 1e9, [&] { k_expand16<8><<<512, 1024>>>((const uint16_t *)b, (double *)a, n8); });
     timeit("expand u16->f64 via LDS, U=2 (r+w)", (bytes + bytes / 4) / 1e9, [&] { k_expand16<2><<<512, 1024>>>((const uint16_t *)b, (double *)a, n8); });
     timeit("expand u16->f64, U=8, 2048 WGs (r+w)", (bytes + bytes / 4) / 1e9, [&] { k_expand16<8><<<2048, 1024>>>((const uint16_t *)b, (double *)a, n8); });
+    const uint64_t ne = 1ull << 30;   // 2^30 entries like R-MAT-26
+    timeit("expand u16->f32 1/lane U=8", ne * 6 / 1e9, [&] { k_expand16_f32<8><<<512, 1024>>>((const uint16_t *)b, (float *)a, ne); });
+    timeit("expand u16->f32 1/lane U=16", ne * 6 / 1e9, [&] { k_expand16_f32<16><<<512, 1024>>>((const uint16_t *)b, (float *)a, ne); });
+    timeit("expand u16->f32 4/lane U=2", ne * 6 / 1e9, [&] { k_expand16x4_f32<2><<<512, 1024>>>((const ushort4 *)b, (float4 *)a, ne / 4); });
+    timeit("expand u16->f32 4/lane U=4", ne * 6 / 1e9, [&] { k_expand16x4_f32<4><<<512, 1024>>>((const ushort4 *)b, (float4 *)a, ne / 4); });
     for (uint32_t run : {16u, 32u, 64u, 128u, 256u, 1024u}) {
         uint64_t nruns = n8 / run;
         char nm[64]; snprintf(nm, sizeof nm, "scattered write runs of %4u x 8B", run);
