@@ -51,6 +51,14 @@ struct gt_program {
     uint64_t x_elems = 0, y_elems = 0;
     uint32_t x_bytes = 4, y_bytes = 4;
     unsigned long long *d_active = nullptr;
+    // PageRank working set in compressed-row space (dense, sequential): the V-space arrays above are
+    // brought up to date lazily (pr_sync_state) when somebody looks at V
+    double *rank_c = nullptr;   // [nnzrows]
+    uint32_t *deg_c = nullptr;  // [nnzrows]
+    uint8_t *C_c = nullptr;     // [nnzrows]
+    bool v_stale = false;       // compressed state is newer than V
+    bool x_fresh = false;       // the owned segment of x already holds the next iteration's messages
+    bool y_clean = false;       // y was zeroed by the fused apply
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
     bool timing = false;
@@ -109,24 +117,48 @@ __global__ void k_apply_deg_col(const uint32_t *__restrict__ y_seg, const uint32
         deg[v] = y_seg[j]; C[v] = 0;
     }
 }
-// pr.h:43-47. cf: TCSC_CF touches regular rows every iteration and source rows (no column,
-// R2C == ~0) on the last one (vp:1671-1691); only regular rows count towards convergence (vp:1902-1916).
-__global__ void k_apply_pr(const double *__restrict__ y, const uint32_t *__restrict__ IR, const uint32_t *__restrict__ R2C,
-                           uint32_t nr, double *__restrict__ rank, uint8_t *__restrict__ C, double alpha, double tol,
-                           int cf, int last, unsigned long long *d_active) {
+// PageRank in compressed-row space: applicator (pr.h:43-47) of iteration t fused with the messenger
+// (pr.h:31-33) of iteration t+1 and with the zero-fill of y (K13): one sequential pass over the rows.
+// A vertex without in-edges has no row: its degree is 0 after initialize(other) (vp:476-483), so its
+// message is the constant 0 written once at initialize; only rows ever produce non-zero messages.
+__global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
+                               double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
+                               double *__restrict__ x_own, double alpha, double tol, int cf, int last,
+                               unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
-        bool source = (R2C[r] == 0xFFFFFFFFu);
-        if (cf && source && !last) continue;
-        uint32_t v = IR[r];
-        double tmp = rank[v];
-        double nv = alpha + (1.0 - alpha) * y[r];
-        rank[v] = nv;
-        uint8_t c = fabs(nv - tmp) > tol;
-        C[v] = c;
-        act += (c && !(cf && source));
+        const uint32_t c = R2C[r];
+        const bool source = (c == 0xFFFFFFFFu);
+        const double yr = y[r];
+        y[r] = 0.0;
+        if (cf && source && !last) continue;   // vp:1671-1691
+        const double tmp = rank_c[r];
+        const double nv = alpha + (1.0 - alpha) * yr;
+        rank_c[r] = nv;
+        const uint8_t ch = fabs(nv - tmp) > tol;
+        C_c[r] = ch;
+        act += (ch && !(cf && source));
+        if (!source) { const uint32_t d = deg_c[r]; x_own[c] = d ? nv / (double)d : 0.0; }
     }
     count_active(act, d_active);
+}
+__global__ void k_pr_pack(const uint32_t *__restrict__ IR, uint32_t nr, const double *__restrict__ rank, const uint32_t *__restrict__ deg,
+                          const uint8_t *__restrict__ C, double *__restrict__ rank_c, uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        const uint32_t v = IR[r];
+        rank_c[r] = rank[v]; deg_c[r] = deg[v]; C_c[r] = C[v];
+    }
+}
+__global__ void k_pr_unpack(const uint32_t *__restrict__ IR, uint32_t nr, const double *__restrict__ rank_c, const uint8_t *__restrict__ C_c,
+                            double *__restrict__ rank, uint8_t *__restrict__ C) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        const uint32_t v = IR[r];
+        rank[v] = rank_c[r]; C[v] = C_c[r];
+    }
+}
+__global__ void k_pr_cf_tail_c(const uint32_t *__restrict__ R2C, uint32_t nr, double *__restrict__ rank_c, double alpha) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x)
+        if (R2C[r] == 0xFFFFFFFFu) rank_c[r] = alpha + (1.0 - alpha) * 0.0;
 }
 __global__ void k_apply_bfs(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
                             uint32_t *__restrict__ parent, uint32_t *__restrict__ hops, uint8_t *__restrict__ C,
@@ -152,12 +184,7 @@ __global__ void k_apply_min(const uint32_t *__restrict__ y, const uint32_t *__re
     }
     count_active(act, d_active);
 }
-// the TCSC_CF converged tail (vp:425-428 -> 1683-1691): source rows get alpha + (1-alpha) * 0
-__global__ void k_pr_cf_tail(const uint32_t *__restrict__ IR, const uint32_t *__restrict__ R2C, uint32_t nr,
-                             double *__restrict__ rank, double alpha) {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x)
-        if (R2C[r] == 0xFFFFFFFFu) rank[IR[r]] = alpha + (1.0 - alpha) * 0.0;
-}
+// the TCSC_CF converged tail (vp:425-428 -> 1683-1691): source rows get alpha + (1-alpha) * 0 (k_pr_cf_tail_c above)
 
 // ------------------------------------------------------------------ init kernels
 template <class T> __global__ void k_fill(T *__restrict__ p, uint64_t n, T v) {
@@ -310,7 +337,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active};
+    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -342,7 +369,11 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
-    if (ok && prm->kind == GT_PR) ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess;
+    if (ok && prm->kind == GT_PR) {
+        const uint64_t nr = std::max<uint32_t>(g->info.nnzrows, 1);
+        ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess && hipMalloc((void **)&p->rank_c, nr * 8) == hipSuccess &&
+             hipMalloc((void **)&p->deg_c, nr * 4) == hipSuccess && hipMalloc((void **)&p->C_c, nr) == hipSuccess;
+    }
     if (!ok) { gt_program_free(p); gt_set_error("out of device memory for program state"); return GT_ERR_HIP; }
     p->x = p->x_own;
     *out = p;
@@ -352,6 +383,24 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
 int gt_program_set_stream(gt_program *p, void *hip_stream) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
     p->stream = (hipStream_t)hip_stream;
+    return GT_OK;
+}
+
+// PageRank: V-space -> compressed working set (after any initialize) and back (before V is read)
+static int pr_pack_state(gt_program *p) {
+    if (p->prm.kind != GT_PR) return GT_OK;
+    const uint32_t nr = p->g->info.nnzrows;
+    if (nr) k_pr_pack<<<grid_for(nr), TPB, 0, p->stream>>>(p->g->IR, nr, p->rank, p->s0, p->C, p->rank_c, p->deg_c, p->C_c);
+    GT_HIP(hipGetLastError());
+    p->v_stale = false; p->x_fresh = false; p->y_clean = false;
+    return GT_OK;
+}
+static int pr_sync_state(gt_program *p) {
+    if (p->prm.kind != GT_PR || !p->v_stale) return GT_OK;
+    const uint32_t nr = p->g->info.nnzrows;
+    if (nr) k_pr_unpack<<<grid_for(nr), TPB, 0, p->stream>>>(p->g->IR, nr, p->rank_c, p->C_c, p->rank, p->C);
+    GT_HIP(hipGetLastError());
+    p->v_stale = false;
     return GT_OK;
 }
 
@@ -381,7 +430,7 @@ static int init_common(gt_program *p) {
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
     p->initialized = true;
-    return GT_OK;
+    return pr_pack_state(p);
 }
 
 int gt_program_initialize(gt_program *p) {
@@ -400,6 +449,8 @@ int gt_program_initialize_from(gt_program *p, const gt_program *other) {
         const uint32_t H = p->g->info.tile_height;
         k_pr_take_degree<<<grid_for(H), TPB, 0, p->stream>>>(H, p->g->IJ, other->s0, p->s0);
         GT_HIP(hipGetLastError());
+        st = pr_pack_state(p);
+        if (st != GT_OK) return st;
     }
     // non-stationary programs ignore `other` (vp:489-493)
     return GT_OK;
@@ -435,11 +486,16 @@ int gt_program_scatter_gather(gt_program *p) {
     const gt_graph *g = p->g;
     const uint32_t nc = g->info.nnzcols;
     if (p->prm.order == GT_COL || nc == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
+    if (p->x_fresh) { p->x_fresh = false; return GT_OK; }  // the fused PageRank apply already wrote them
     const uint64_t off = (uint64_t)g->info.rank * g->info.seg_stride;
     hipStream_t s = p->stream;
     switch (p->prm.kind) {
         case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, nc); break;
-        case GT_PR: k_msg_pr<<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank); break;
+        case GT_PR: {
+            int st = pr_sync_state(p); if (st != GT_OK) return st;
+            k_msg_pr<<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank);
+            break;
+        }
         default:
             k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, g->JC, nc, p->C, p->s0,
                                                    g->info.rank * g->info.tile_height, p->prm.kind);
@@ -458,7 +514,8 @@ static int combine_impl(gt_program *p, bool timed) {
         GT_HIP(hipGetLastError());
         return GT_OK;
     }
-    if (p->stationary) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
+    if (p->stationary && !p->y_clean) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
+    p->y_clean = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         if (p->ev_used + 2 > p->ev.size()) {
@@ -515,8 +572,11 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             break;
         case GT_PR: {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
-            if (nr) k_apply_pr<<<grid_for(nr), TPB, 0, s>>>((const double *)p->y, g->IR, g->R2C, nr, p->rank, p->C, p->prm.alpha,
-                                                            p->prm.tol, cf, last, p->d_active);
+            // x may be a caller-installed buffer (multi-rank): the owned segment starts at rank * seg_stride
+            double *x_own_seg = (double *)p->x + (uint64_t)g->info.rank * g->info.seg_stride;
+            if (nr) k_pr_apply_msg<<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, x_own_seg,
+                                                                p->prm.alpha, p->prm.tol, cf, last, p->d_active);
+            p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
         }
         case GT_BFS:
@@ -541,8 +601,9 @@ int gt_program_finish_converged(gt_program *p) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "finish before initialize");
     p->converged = true;
     if (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF && p->g->info.nnzrows) {
-        k_pr_cf_tail<<<grid_for(p->g->info.nnzrows), TPB, 0, p->stream>>>(p->g->IR, p->g->R2C, p->g->info.nnzrows, p->rank, p->prm.alpha);
+        k_pr_cf_tail_c<<<grid_for(p->g->info.nnzrows), TPB, 0, p->stream>>>(p->g->R2C, p->g->info.nnzrows, p->rank_c, p->prm.alpha);
         GT_HIP(hipGetLastError());
+        p->v_stale = true;
     }
     return GT_OK;
 }
@@ -597,6 +658,7 @@ int gt_program_copy_state(gt_program *p, int field, void *host_out, uint64_t cou
         default: break;
     }
     GT_REQUIRE(src, GT_ERR_INVALID, "field %d does not exist for program kind %d", field, k);
+    { int st = pr_sync_state(p); if (st != GT_OK) return st; }
     GT_HIP(hipStreamSynchronize(p->stream));
     GT_HIP(hipMemcpy(host_out, src, count * w, hipMemcpyDeviceToHost));
     return GT_OK;
@@ -608,6 +670,7 @@ int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable)
     const uint32_t H = i.tile_height;
     const uint64_t base = (uint64_t)i.rank * H;
     uint64_t s = 0, c = 0;
+    { int st = pr_sync_state(p); if (st != GT_OK) return st; }
     GT_HIP(hipStreamSynchronize(p->stream));
     if (p->prm.kind == GT_PR) {  // get_state() = rank (pr.h:17), infinity() = 0 (vp:40)
         std::vector<double> h(H);
