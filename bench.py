@@ -8,7 +8,10 @@ A STEP is one PageRank iteration of the hot path (scatter_gather -> combine/SpMV
 /root/reference/src/vp/vertex_program.hpp:417-421) over the whole graph. The workload is the one
 the metric is quoted on: PageRank, R-MAT scale 26, edge factor 16, (a,b,c,d)=(.57,.19,.19,.05),
 seed 1, flags of apps/pr.cpp (directed, transposed, self loops and parallel edges
-kept, TCSC_CF); the reference's `fp` is double (apps/deg.h:19) and so is ours ("dtype": "f64").
+kept, TCSC_CF). The reference's `fp` is double (apps/deg.h:19): ranks, accumulators and y are f64
+here too; by default the per-edge messages are rounded to f32 in flight (--spmv pb_f32msg, max
+relative rank error 3.7e-8 against the fp64 oracle, tests/test_gpu_parity.py; BASELINE.json quotes
+the GPU configuration as fp32 with a 1e-6 tolerance). --spmv pb keeps the messages in f64.
 For N > 1 the SAME graph is split by tile-rows over the N GPUs (strong scaling); the only
 collective on the data path is the all-gather of the message vector x (graphtap_amd/dist.py).
 
@@ -33,33 +36,83 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(scale, seed, budget_iters=3):
-    """Oracle ("port") PageRank on a bounded sample of the same workload, timed like the reference's
-    Execute time (iteration loop only), single thread."""
+def _cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
+
+
+def _sample_edges(scale, seed, count):
+    """The first `count` records of the workload's R-MAT stream, generated on the GPU (bit-identical to
+    graphtap_amd/rmat.py) and copied to the host."""
     import numpy as np
-    from graphtap_amd.rmat import rmat_edges
+    from graphtap_amd import _lib
+    L = _lib.lib()
+    d = C.c_void_p()
+    _lib.check(L.gt_malloc(C.byref(d), count * 8))
+    _lib.check(L.gt_rmat_generate(d, scale, seed, 0, 0, count, None))
+    e = np.empty((count, 2), np.uint32)
+    _lib.check(L.gt_memcpy_d2h(e.ctypes.data_as(C.c_void_p), d, count * 8))
+    _lib.check(L.gt_free(d))
+    return e
+
+
+def cpu_baseline_port(e, scale, seed, iters=3):
+    """Oracle ("port") PageRank, timed like the reference's Execute time (iteration loop only), one thread."""
     from oracle import oracle as O
-    sample_edges = min(16 << scale, 1 << 26)   # first 2^26 records of the same R-MAT stream
-    nv = 1 << scale
-    chunks = []
-    step = 1 << 22
-    for first in range(0, sample_edges, step):
-        chunks.append(rmat_edges(scale, 16, seed, first=first, count=min(step, sample_edges - first)))
-    e = np.concatenate(chunks)
-    g = O.OracleGraph(e, nv, **O.APP_FLAGS["pr"])
+    g = O.OracleGraph(e, 1 << scale, **O.APP_FLAGS["pr"])
     d = g.degree(1)
     t0 = time.perf_counter()
-    _, _, it = g.pagerank(d, budget_iters, cf=True)
+    _, _, it = g.pagerank(d, iters, cf=True)
     dt = time.perf_counter() - t0
     nnz = g.nnz
     g.close()
-    try:
-        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        model = "unknown"
     return {"value": nnz * it / dt / 1e9, "unit": "GTEPS", "cores": 1, "kind": "port",
             "sample": "oracle/gt_oracle.c PageRank, first %d records of the same R-MAT-%d stream (seed %d), %d iterations, %.1f s, %s"
-                      % (sample_edges, scale, seed, it, dt, model)}
+                      % (len(e), scale, seed, it, dt, _cpu_model())}
+
+
+def cpu_baseline_reference(e, scale, seed, iters=20, nproc=8):
+    """The UNMODIFIED reference (oracle/_ref/pr, built by oracle/ref/Makefile in the build container) run
+    under the image's MPICH on this box's host cores; its own "Execute time" line is the timer."""
+    import re
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    exe, mpirun = os.path.join(ref, "pr"), "/opt/conda/bin/mpirun"
+    if not (os.path.exists(exe) and os.path.exists(mpirun)):
+        return None
+    with tempfile.TemporaryDirectory(prefix="gtref") as tmp:
+        path = os.path.join(tmp, "sample.bin")
+        e.tofile(path)
+        env = dict(os.environ, PATH=os.path.join(ref, "fileshim") + ":" + os.environ.get("PATH", ""))
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run([mpirun, "-np", str(nproc), exe, path, str(1 << scale), str(iters)], env=env,
+                               capture_output=True, text=True, timeout=240)
+            wall = time.perf_counter() - t0
+        except Exception:
+            return None
+    ex = re.findall(r"^Execute time: ([0-9.eE+-]+) seconds", r.stdout, re.M)
+    its = re.findall(r"^Iterations: (\d+)", r.stdout, re.M)
+    ing = re.findall(r"^Ingress time: ([0-9.eE+-]+) seconds", r.stdout, re.M)
+    if r.returncode != 0 or len(ex) < 2 or not its or int(its[-1]) != iters:
+        return None
+    t = float(ex[-1])   # the PageRank pass (the first Execute line is the Degree pass)
+    return {"value": len(e) * iters / t / 1e9, "unit": "GTEPS", "cores": nproc, "kind": "reference",
+            "sample": "unmodified GraphTap `pr` (mpirun -np %d), first %d records of the same R-MAT-%d stream (seed %d), %d iterations, "
+                      "Execute %.2f s, Ingress %s s, wall %.0f s, %s" % (nproc, len(e), scale, seed, iters, t, ing[-1] if ing else "?", wall, _cpu_model())}
+
+
+def cpu_baseline(scale, seed):
+    sample = min(16 << scale, 1 << 27)   # bounded sample: the first 2^27 records (1 GiB) of the same stream
+    e = _sample_edges(scale, seed, sample)
+    port = cpu_baseline_port(e[:min(sample, 1 << 26)], scale, seed)
+    ref = cpu_baseline_reference(e, scale, seed)
+    if ref is None:
+        return port, None
+    return ref, port
 
 
 def main():
@@ -71,7 +124,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
-    ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb"),
+    ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb_f32msg"),
                     help="SpMV implementation (gt_spmv_variant): propagation blocking (default), the same with f32 messages, or the edge-atomic baseline")
     args = ap.parse_args()
 
@@ -183,7 +236,11 @@ def main():
                      "kernel_ms": kernel_ms, "launches": launches},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scale, args.seed)
+        VR.free(); G.free()   # give the HBM back before the host-side runs
+        main_b, port_b = cpu_baseline(scale, args.seed)
+        out["cpu_baseline"] = main_b
+        if port_b is not None:
+            out["cpu_baseline_port"] = port_b
     VR.free(); G.free()
     if world > 1:
         dist.barrier()
