@@ -62,6 +62,7 @@ struct gt_program {
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
     bool timing = false;
+    bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
 };
 
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
@@ -70,11 +71,12 @@ struct gt_program {
 __global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[j] = 1u;  // deg.h:35-37
 }
-__global__ void k_msg_pr(double *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
+template <class TX>
+__global__ void k_msg_pr(TX *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
                          const uint32_t *__restrict__ deg, const double *__restrict__ rank) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j], d = deg[v];
-        x[j] = d ? rank[v] / (double)d : 0.0;  // pr.h:31-33
+        x[j] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
     }
 }
 __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
@@ -121,9 +123,10 @@ __global__ void k_apply_deg_col(const uint32_t *__restrict__ y_seg, const uint32
 // (pr.h:31-33) of iteration t+1 and with the zero-fill of y (K13): one sequential pass over the rows.
 // A vertex without in-edges has no row: its degree is 0 after initialize(other) (vp:476-483), so its
 // message is the constant 0 written once at initialize; only rows ever produce non-zero messages.
+template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
-                               double *__restrict__ x_own, double alpha, double tol, int cf, int last,
+                               TX *__restrict__ x_own, double alpha, double tol, int cf, int last,
                                unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
@@ -138,7 +141,7 @@ __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restric
         const uint8_t ch = fabs(nv - tmp) > tol;
         C_c[r] = ch;
         act += (ch && !(cf && source));
-        if (!source) { const uint32_t d = deg_c[r]; x_own[c] = d ? nv / (double)d : 0.0; }
+        if (!source) { const uint32_t d = deg_c[r]; x_own[c] = (TX)(d ? nv / (double)d : 0.0); }
     }
     count_active(act, d_active);
 }
@@ -357,7 +360,11 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
     p->stationary = (prm->kind == GT_DEG || prm->kind == GT_PR);  // apps/*.cpp
     switch (prm->kind) {
         case GT_DEG: p->semiring = GT_PLUS_U32; break;
-        case GT_PR: p->semiring = GT_PLUS_F64; p->x_bytes = p->y_bytes = 8; break;
+        case GT_PR:
+            p->semiring = GT_PLUS_F64; p->y_bytes = 8;
+            p->x_f32 = (g->spmv_variant == GT_SPMV_PB_F32MSG);
+            p->x_bytes = p->x_f32 ? 4 : 8;
+            break;
         case GT_SSSP: p->semiring = GT_MINPLUS_U32; break;
         default: p->semiring = GT_MIN_U32; break;
     }
@@ -425,6 +432,7 @@ static int init_common(gt_program *p) {
     }
     // messages: padding columns are never referenced; give them the semiring's neutral message
     if (p->x_bytes == 8) k_fill<double><<<grid_for(p->x_elems), TPB, 0, s>>>((double *)p->x, p->x_elems, 0.0);
+    else if (p->x_f32) k_fill<float><<<grid_for(p->x_elems), TPB, 0, s>>>((float *)p->x, p->x_elems, 0.0f);
     else k_fill<uint32_t><<<grid_for(p->x_elems), TPB, 0, s>>>((uint32_t *)p->x, p->x_elems, p->stationary ? 0u : GT_INF);
     // accumulators: init_nonstationary fills y with infinity() (vp:625-635); stationary y is zeroed per combine
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
@@ -493,7 +501,8 @@ int gt_program_scatter_gather(gt_program *p) {
         case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, nc); break;
         case GT_PR: {
             int st = pr_sync_state(p); if (st != GT_OK) return st;
-            k_msg_pr<<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank);
+            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)p->x + off, g->JC, nc, p->s0, p->rank);
+            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank);
             break;
         }
         default:
@@ -526,7 +535,7 @@ static int combine_impl(gt_program *p, bool timed) {
         e0 = p->ev[p->ev_used]; e1 = p->ev[p->ev_used + 1]; p->ev_used += 2;
         GT_HIP(hipEventRecord(e0, s));
     }
-    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s);
+    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32);
     if (st != GT_OK) return st;
     if (timed) GT_HIP(hipEventRecord(e1, s));
     return GT_OK;
@@ -573,9 +582,13 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         case GT_PR: {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
             // x may be a caller-installed buffer (multi-rank): the owned segment starts at rank * seg_stride
-            double *x_own_seg = (double *)p->x + (uint64_t)g->info.rank * g->info.seg_stride;
-            if (nr) k_pr_apply_msg<<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, x_own_seg,
-                                                                p->prm.alpha, p->prm.tol, cf, last, p->d_active);
+            const uint64_t xoff = (uint64_t)g->info.rank * g->info.seg_stride;
+            if (nr && p->x_f32)
+                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)p->x + xoff,
+                                                                   p->prm.alpha, p->prm.tol, cf, last, p->d_active);
+            else if (nr)
+                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)p->x + xoff,
+                                                                    p->prm.alpha, p->prm.tol, cf, last, p->d_active);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
         }

@@ -177,21 +177,21 @@ template <> struct Msg<double, double> { static __device__ __forceinline__ doubl
 template <> struct Msg<double, float> { static __device__ __forceinline__ float val(float x, uint32_t) { return x; } };
 template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
 
-template <class T, class TV, bool WEIGHTED>
+template <class T, class TV, class TX, bool WEIGHTED>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nnz,
                                                            const uint16_t *__restrict__ LCOL, const uint32_t *__restrict__ WT,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
-                                                           const T *__restrict__ x, TV *__restrict__ VAL) {
+                                                           const TX *__restrict__ x, TV *__restrict__ VAL) {
     __shared__ TV xwin[W];
     const uint32_t c = blockIdx.x;
     const uint32_t v0 = cv0[c], v1 = cv1[c], col0 = ccol0[c];
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
     {   // stage the window: all loads of a lane in flight together
         constexpr int PER = W / P1_THREADS;
-        T t[PER];
+        TX t[PER];
 #pragma unroll
-        for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; t[i] = (j < wn) ? x[col0 + j] : T(0); }
+        for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; t[i] = (j < wn) ? x[col0 + j] : TX(0); }
 #pragma unroll
         for (int i = 0; i < PER; i++) xwin[threadIdx.x + i * P1_THREADS] = (TV)t[i];
     }
@@ -481,16 +481,16 @@ int gt_pb_build(gt_graph *g) {
     return GT_OK;
 }
 
-template <class T, class TV, bool WEIGHTED, bool IS_MIN>
-static int pb_run(const gt_graph *g, gt_pb *pb, const T *x, T *y, hipStream_t s) {
-    k_pb_scatter<T, TV, WEIGHTED><<<pb->nchunks, P1_THREADS, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->nnz, pb->LCOL, pb->WT,
+template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
+static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s) {
+    k_pb_scatter<T, TV, TX, WEIGHTED><<<pb->nchunks, P1_THREADS, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->nnz, pb->LCOL, pb->WT,
                                                                      pb->KSTART, (const GroupRec *)pb->G, x, (TV *)pb->VAL);
     k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, pb->LROW, (const TV *)pb->VAL, g->info.nnzrows, y);
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
-int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages) {
+int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -503,13 +503,15 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     }
     switch (semiring) {
         case GT_PLUS_F64:
-            if (f32_messages) return pb_run<double, float, false, false>(g, pb, (const double *)x, (double *)y, s);
-            return pb_run<double, double, false, false>(g, pb, (const double *)x, (double *)y, s);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+            GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

@@ -46,7 +46,13 @@ class _HipEngine:
         import torch
         ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
         check(getter(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
-        return torch.as_tensor(_CudaArray(ptr.value, n.value, "<f8" if w.value == 8 else "<i4"), device="cuda")
+        return torch.as_tensor(_CudaArray(ptr.value, n.value, self._typestr(w.value)), device="cuda")
+
+    def _typestr(self, width):
+        # PageRank messages are floating point (f64, or f32 under GT_SPMV_PB_F32MSG); everything else is u32 viewed as i32
+        if self.prog.kind == GT_PR:
+            return "<f8" if width == 8 else "<f4"
+        return "<i4"
 
     def x_tensor(self):
         """The message vector handed to the collective. For a multi-rank run it is a torch allocation
@@ -57,7 +63,7 @@ class _HipEngine:
                 import torch
                 ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
                 check(lib().gt_program_x(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
-                own = torch.as_tensor(_CudaArray(ptr.value, n.value, "<f8" if w.value == 8 else "<i4"), device="cuda")
+                own = torch.as_tensor(_CudaArray(ptr.value, n.value, self._typestr(w.value)), device="cuda")
                 self._x = own.clone()            # keeps whatever initialize() put there
                 check(lib().gt_program_set_x(self.prog._h, C.c_void_p(self._x.data_ptr())))
             else:

@@ -176,8 +176,9 @@ int gt_program_enable_timing(gt_program *p, int on);
 int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int reset);
 
 /* phase level, for the multi-GPU driver (graphtap_amd/dist.py) ------------
- * x is one device buffer of nranks*seg_stride messages (f64 for PageRank, u32
- * otherwise), segment s at [s*seg_stride, (s+1)*seg_stride). The engine owns a
+ * x is one device buffer of nranks*seg_stride messages (f64 for PageRank -- f32
+ * when the graph's SpMV variant is GT_SPMV_PB_F32MSG at program creation -- u32
+ * otherwise; gt_program_x reports the element width), segment s at [s*seg_stride, (s+1)*seg_stride). The engine owns a
  * default buffer; a caller that exchanges through its own allocation (a torch
  * tensor handed to RCCL) installs it with gt_program_set_x. */
 int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);

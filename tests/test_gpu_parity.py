@@ -264,9 +264,10 @@ def test_midsize_rmat_against_oracle(gt, O, scale, seed):
 
 
 # ------------------------------------------------------------------------------- multi-rank layout on one GPU
+@pytest.mark.parametrize("variant", ["pb", "pb_f32msg", "edge"])
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 @pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
-def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks):
+def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, variant, monkeypatch):
     """Every rank's tile-row on the same GPU, with the all-gather of x done by device copies: checks
     the p-rank data layout (H = nrows/p + 1, [segment][seg_stride] columns, owned-segment state)
     of the engine without RCCL. BFS labels must equal the reference's np=1 run bit for bit;
@@ -274,6 +275,7 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks):
     import torch
     from graphtap_amd import dist as gdist
     from graphtap_amd.vertex_program import _HipEngine
+    monkeypatch.setenv("GRAPHTAP_SPMV", variant)   # read by gt_graph_build
     c = load_case(name); nv = c["num_vertices"]; n = nv + 1
 
     class Loopback:
