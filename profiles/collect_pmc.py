@@ -20,6 +20,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -28,7 +29,8 @@ def per_kernel(d, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0].split("::")[-1]].append(float(r["Counter_Value"]))
+            m = re.search(r"\b(k_[A-Za-z0-9_]+)", r["Kernel_Name"])
+            acc[m.group(1) if m else r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) * 1024.0 for k, v in acc.items()}   # mean bytes per launch
 
 
