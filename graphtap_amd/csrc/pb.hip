@@ -5,11 +5,11 @@
 // stream and every random access hits LDS:
 //
 //   phase 1  "scatter"   one workgroup per CHUNK of the column-major entry stream (a window of
-//            W = 16384 consecutive compressed columns, split every CH <= 2^20 entries): the window's messages
+//            W = 8192 consecutive compressed columns, split every CH <= 2^20 entries): the window's messages
 //            x[col0 .. col0+W) are staged in LDS (coalesced load), then for every entry, in
 //            (chunk, row-bin) order, VAL[k] = x[col] (+ w) is written at the entry's slot k of the
 //            row-bin-major value stream. A lane handles a QUAD of four consecutive entries: one 8-byte
-//            load of window-local column ids, four LDS reads, one 16-byte (f32/u32) or 32-byte (f64) store.
+//            load of window-local column ids, four LDS reads, up to four 4/8-byte stores (one per row group).
 //   phase 2  "gather"    one workgroup per ROW BIN (R = 16384 consecutive compressed rows; heavy
 //            bins are split by entry count): the bin's partial accumulators live in LDS (R x F =
 //            128 KiB for f64), the bin's slice of VAL and of the static bin-local row ids LROW is
@@ -17,20 +17,23 @@
 //            ds_min_u32), then merged into y (plain RMW when the bin has one workgroup, device atomics
 //            when it was split).
 //
-// A RUN is the set of entries of one (chunk, bin) pair; it is contiguous in both orders. Runs are padded
-// to a multiple of four entries in both orders (pad entries read the neutral message from a spare LDS
-// slot and add it to row 0 of the bin: no effect), so a quad never straddles two runs and every access
-// is naturally aligned. Static per-graph data, built once on the device (rocPRIM sorts / scans):
-//   LCOL[v]  u16  v-order = runs sorted by (chunk, bin), entries inside by (col, row); low 15 bits:
-//                 col - col0 (16384 = pad), bit 15: first entry of a run
-//   LROW[k]  u16  k-order = runs sorted by (bin, chunk); row & (R-1)
+// A RUN is the set of entries of one (chunk, bin) pair; it is contiguous in both orders and, inside a run,
+// entries are sorted by (row, col). Phase 1 PRE-AGGREGATES: consecutive entries of a quad that hit the same
+// row are combined (+ or min) in registers and leave ONE value, so the value stream and LROW have one slot
+// per (quad, row) group instead of one per entry (R-MAT-26: 1.07 G entries -> see [pb] stats). Runs are
+// padded to a multiple of four entries in the v-order and to a multiple of four outputs in the k-order (pad
+// inputs read the neutral message from a spare LDS slot; pad outputs are pre-filled with the neutral value
+// and target row 0 of the bin: no effect), so quads never straddle runs and every access is aligned.
+// Static per-graph data, built once on the device (rocPRIM sorts / scans):
+//   LCOL[v]  u16  v-order = runs sorted by (chunk, bin), entries inside by (row, col); bits 0-13: col - col0
+//                 (8192 = pad), bit 14: last entry of its (quad, row) group, bit 15: first entry of a run
+//   LROW[k]  u16  k-order = outputs, runs sorted by (bin, chunk); row & (R-1)
 //   WT[v]    u32  weights in v-order (min-plus only)
-//   G[g]     32 B per 256 entries of the v-order: the k-quad of lane 0 and of the first six run heads
-//                 of the group, so that no load of phase 1 depends on another load
-//   KSTARTQ[s]    k-quad where run s starts (groups with seven or more run heads only)
-// HBM traffic per entry per SpMV: 2 + 0.125 + F (phase 1) + F + 2 (phase 2), F = bytes of a message in
-// flight: 20.1 B (f64), 12.1 B (u32, or PageRank with f32 messages), against the 4.5 B of the algorithmic
-// minimum.
+//   G[g]     32 B per 256 entries of the v-order: the k-slot of lane 0's first output and of the first six
+//                 run heads of the group, so that no load of phase 1 depends on another load
+//   KSTART[s]     k-slot where run s starts (groups with seven or more run heads only)
+// HBM traffic per entry per SpMV: 2 + 0.125 (phase 1 in) + (F + F + 2) / D (value stream out and back, LROW),
+// D = entries per output, F = bytes of a message in flight.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -44,7 +47,7 @@ namespace {
 
 constexpr int RB = 14;                 // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS
-constexpr uint32_t W = 16384;          // columns per window: 64 KiB (4-byte messages) or 128 KiB (f64) of LDS
+constexpr uint32_t W = 8192;           // columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
 // Entries per chunk: large chunks make long runs (mean run ~300 entries at 2^20 on R-MAT-26), but the grid
 // must still be several times the 512 resident phase-1 workgroups: aim at >= ~1024 entry-limited chunks.
 static uint32_t ch_default(uint32_t nnz) {
@@ -58,7 +61,8 @@ constexpr uint32_t EPW = 1u << 18;     // (padded) entries per phase-2 workgroup
 constexpr int P1_THREADS = 1024;
 constexpr int P2_THREADS = 1024;
 constexpr uint16_t HEAD = 0x8000;
-constexpr uint16_t COLMASK = 0x7FFF;
+constexpr uint16_t COLMASK = 0x3FFF;
+constexpr uint16_t GEND = 0x4000;      // last entry of its (quad, row) group
 constexpr uint16_t PADCOL = W;         // LDS slot W holds the semiring's neutral message
 constexpr int TPB = 256;
 
@@ -76,7 +80,7 @@ struct DevBuf {
     template <class T> T *as() { return (T *)p; }
 };
 
-struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes, quad units
+struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes, k-slots in output units
 struct BinWork { uint32_t bin, k0, k1, single; };
 
 // ------------------------------------------------------------------ build kernels
@@ -100,14 +104,20 @@ __global__ void k_fill_chunks(const uint32_t *__restrict__ JA, uint32_t ncols, u
         }
     }
 }
-// sort key of every entry: (chunk << binbits) | row bin
+// sort key of every entry: (chunk, row bin, row inside the bin) -> runs come out sorted by (row, col)
 __global__ void k_keys(const uint32_t *__restrict__ ce0, const uint32_t *__restrict__ ce1, const uint32_t *__restrict__ IA,
-                       int binbits, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+                       int binbits, uint64_t *__restrict__ key, uint32_t *__restrict__ idx) {
     const uint32_t c = blockIdx.x;
     for (uint64_t e = (uint64_t)ce0[c] + threadIdx.x; e < ce1[c]; e += blockDim.x) {
-        key[e] = (c << binbits) | (IA[e] >> RB);
+        const uint32_t r = IA[e];
+        key[e] = ((((uint64_t)c << binbits) | (r >> RB)) << RB) | (r & (R - 1));
         idx[e] = (uint32_t)e;
     }
+}
+// run key (chunk, bin) of every sorted entry
+__global__ void k_run_keys(const uint64_t *__restrict__ key64, uint64_t n, uint32_t *__restrict__ key) {
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
+        key[v] = (uint32_t)(key64[v] >> RB);
 }
 __global__ void k_iota(uint32_t *__restrict__ p, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
@@ -160,22 +170,40 @@ __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nru
         cv0[c] = pvstart[a]; cv1[c] = pvstart[b];
     }
 }
-__global__ void k_static_streams(const uint32_t *__restrict__ key, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ sid,
-                                 uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ IA,
-                                 const uint32_t *__restrict__ JI, const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart,
-                                 const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart,
+// E[pv] = 1 when the entry at padded v-position pv is the last of its (quad, row) group
+__global__ void k_group_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n,
+                             const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart,
+                             uint32_t *__restrict__ E) {
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = sid[v] - 1, o = (uint32_t)v - vstart[s], pv = pvstart[s] + o;
+        const bool last_of_run = (o + 1 == len[s]);
+        const bool last_of_quad = ((pv & 3) == 3);
+        const bool row_changes = !last_of_run && ((key64[v + 1] & (R - 1)) != (key64[v] & (R - 1)));
+        E[pv] = (last_of_run || last_of_quad || row_changes) ? 1u : 0u;
+    }
+}
+// outputs of run s = X[pvstart[s+1]] - X[pvstart[s]] (X = exclusive scan of E), padded to a multiple of 4
+__global__ void k_run_outputs(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ X, uint32_t nrun,
+                              uint32_t *__restrict__ noutpad) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nrun; s += gridDim.x * blockDim.x)
+        noutpad[s] = (X[pvstart[s + 1]] - X[pvstart[s]] + 3) & ~3u;
+}
+__global__ void k_static_streams(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ sid,
+                                 uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ JI,
+                                 const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ pvstart,
+                                 const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ E, const uint32_t *__restrict__ X,
                                  uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW, uint32_t *__restrict__ WT) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t e = idx[v], c = key[v] >> binbits, s = sid[v] - 1, o = (uint32_t)v - vstart[s];
-        const uint32_t pv = pvstart[s] + o, pk = pkstart[s] + o;
-        LCOL[pv] = (uint16_t)((JI[e] - ccol0[c]) | (o == 0 ? HEAD : 0));
-        LROW[pk] = (uint16_t)(IA[e] & (R - 1));
+        const uint32_t e = idx[v], c = (uint32_t)(key64[v] >> (RB + binbits)), s = sid[v] - 1, o = (uint32_t)v - vstart[s];
+        const uint32_t pv = pvstart[s] + o, ge = E[pv];
+        LCOL[pv] = (uint16_t)((JI[e] - ccol0[c]) | (ge ? GEND : 0) | (o == 0 ? HEAD : 0));
+        if (ge) LROW[pkstart[s] + (X[pv] - X[pvstart[s]])] = (uint16_t)(key64[v] & (R - 1));
         if (WT) WT[pv] = A[e];
     }
 }
-// Group table: one record per 256 padded entries (64 lanes x 4) of the v-order, quad units.
-__global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, uint32_t nrun, uint32_t np,
-                              GroupRec *__restrict__ G) {
+// Group table: one record per 256 padded entries (64 lanes x 4) of the v-order, k-slots in output units.
+__global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ X,
+                              uint32_t nrun, uint32_t np, GroupRec *__restrict__ G) {
     const uint64_t ngroups = ((uint64_t)np + 255) / 256;
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t pv = (uint32_t)(g * 256);
@@ -184,13 +212,10 @@ __global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32
         while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (pvstart[mid] <= pv) lo = mid + 1; else hi = mid; }
         const uint32_t s0 = lo - 1;
         GroupRec r;
-        r.s = s0; r.k0 = (pkstart[s0] + (pv - pvstart[s0])) >> 2;
-        for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nrun) ? (pkstart[s0 + 1 + i] >> 2) : 0;
+        r.s = s0; r.k0 = pkstart[s0] + (X[pv] - X[pvstart[s0]]);
+        for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nrun) ? pkstart[s0 + 1 + i] : 0;
         G[g] = r;
     }
-}
-__global__ void k_shr2(uint32_t *__restrict__ p, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] >>= 2;
 }
 
 // ------------------------------------------------------------------ phase 1
@@ -211,12 +236,14 @@ template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nquads,
                                                            const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
-                                                           const uint32_t *__restrict__ KSTARTQ, const GroupRec *__restrict__ G,
-                                                           const TX *__restrict__ x, V4<TV> *__restrict__ VAL4) {
+                                                           const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
+                                                           const TX *__restrict__ x, TV *__restrict__ VAL) {
     __shared__ TV xwin[W + 64];
+    __shared__ TV stage[P1_THREADS / 64][256];   // per-wave compaction row for the outputs of one 256-entry group
     const uint32_t c = blockIdx.x;
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
+    const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     {   // stage the window: all loads of a lane in flight together
         constexpr int PER = W / P1_THREADS;
         TX t[PER];
@@ -224,14 +251,13 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; t[i] = (j < wn) ? x[col0 + j] : TX(0); }
 #pragma unroll
         for (int i = 0; i < PER; i++) xwin[threadIdx.x + i * P1_THREADS] = (TV)t[i];
-        if (threadIdx.x == 0) xwin[PADCOL] = IS_MIN ? (TV)GT_INF : (TV)0;
+        if (threadIdx.x == 0) xwin[PADCOL] = neutral;
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 2;   // 256-entry groups in flight per wave
-    const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);  // lanes 0..lane
     const uint32_t gend = (q1c + 63) >> 6;
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
     // Groups are aligned to 64 quads in v-space; a group at a chunk border is visited by both chunks,
@@ -259,20 +285,55 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const uint32_t g = g0 + u;
             if (g >= gend) break;
             const uint32_t q = g * 64 + lane;
+            const bool live = q < nquads;
             const bool mine = (q >= q0c && q < q1c);
-            const uint64_t heads = __ballot(q < nquads && (lc[u].c[0] & HEAD) != 0) & lane_le & ~1ull;  // run heads in lanes 1..lane
-            const uint32_t cnt = __popcll(heads);
-            const uint32_t hpos = heads ? 63 - __clzll(heads) : 0;
-            // dword 0 = k-quad of lane 0; dword i (1..6) = k-quad of the i-th head; dword 7 = run of lane 0
-            const uint32_t ks = __shfl(gw[u], cnt < 7 ? cnt : 7);
-            const bool rare = (cnt >= 7);   // seven or more runs inside 256 entries
-            V4<TV> val;
+            // group-end bits of the quad and the number of outputs of this lane
+            const uint32_t e0 = live && (lc[u].c[0] & GEND), e1 = live && (lc[u].c[1] & GEND), e2 = live && (lc[u].c[2] & GEND),
+                           e3 = live && (lc[u].c[3] & GEND);
+            const uint32_t n = e0 + e1 + e2 + e3;
+            uint32_t p = n;   // inclusive prefix of n over the wave
 #pragma unroll
-            for (int j = 0; j < 4; j++) val.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & COLMASK], w[u].w[j]);
-            if (__ballot(rare) != 0) {      // wave-uniform branch: the dependent load and its wait stay in here
-                if (rare && mine) VAL4[KSTARTQ[ks + cnt] + (lane - hpos)] = val;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(p, d); if (lane >= (uint32_t)d) p += t; }
+            const uint32_t pex = p - n;
+            // segmented combine over the quad: one output per (quad, row) group, compacted into the wave's LDS
+            // staging row at [pex, pex + n) so that the stores below are fully coalesced
+            TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
+               v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
+            auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
+            TV *st = stage[wave];
+            __builtin_amdgcn_wave_barrier();
+            TV acc = v0;
+            if (e0) st[pex] = acc;
+            acc = e0 ? v1 : comb(acc, v1);
+            if (e1) st[pex + e0] = acc;
+            acc = e1 ? v2 : comb(acc, v2);
+            if (e2) st[pex + e0 + e1] = acc;
+            acc = e2 ? v3 : comb(acc, v3);
+            if (e3) st[pex + e0 + e1 + e2] = acc;
+            __builtin_amdgcn_wave_barrier();
+            // this chunk's quads are a contiguous lane range -> a contiguous range [mlo, mhi) of the compacted outputs
+            const uint64_t M = __ballot(mine);
+            if (M != 0) {
+                const int l0 = __ffsll((unsigned long long)M) - 1, l1 = 63 - __clzll((unsigned long long)M);
+                const uint32_t mlo = __builtin_amdgcn_readlane(pex, l0), mhi = __builtin_amdgcn_readlane(p, l1);
+                const uint64_t H = __ballot(live && (lc[u].c[0] & HEAD) != 0) & ~1ull;   // run heads in lanes 1..63
+                // dword 0 of the group record = k-slot of the group's first output; dword i (1..6) = k-slot of the i-th
+                // run head; dword 7 = run of lane 0 (for the rare groups with seven or more heads)
+                const uint32_t k0 = __builtin_amdgcn_readlane(gw[u], 0);
+                for (uint32_t m = mlo + lane; m < mhi; m += 64) {
+                    uint32_t base = k0, off = 0;
+                    uint64_t Hm = H;
+                    int i = 0;
+                    while (Hm) {   // wave-uniform loop over the run heads of the group (usually 0-2)
+                        const int hl = __ffsll((unsigned long long)Hm) - 1;
+                        Hm &= Hm - 1; i++;
+                        const uint32_t Bi = __builtin_amdgcn_readlane(pex, hl);
+                        const uint32_t KSi = (i < 7) ? __builtin_amdgcn_readlane(gw[u], i) : KSTART[__builtin_amdgcn_readlane(gw[u], 7) + i];
+                        if (m >= Bi) { base = KSi; off = Bi; }
+                    }
+                    VAL[base + (m - off)] = st[m];
+                }
             }
-            if (!rare && mine) VAL4[ks + (lane - hpos)] = val;
         }
         g0 = gn;
 #pragma unroll
@@ -333,19 +394,22 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
 
 struct gt_pb {
     uint32_t nbins = 0, nchunks = 0, nwork = 0, nnz = 0;
-    uint32_t np = 0;           // padded entries (multiple of 4)
+    uint32_t np = 0;           // padded entries of the v-order (multiple of 4)
+    uint32_t nout = 0;         // padded outputs of the k-order (multiple of 4): slots of VAL / LROW
     uint32_t *cv0 = nullptr, *cv1 = nullptr, *ccol0 = nullptr;
     uint16_t *LCOL = nullptr, *LROW = nullptr;
-    uint32_t *WT = nullptr, *KSTARTQ = nullptr;
+    uint32_t *WT = nullptr, *KSTART = nullptr;
     void *G = nullptr;         // GroupRec per 256 padded entries
     BinWork *work = nullptr;
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
+    int val_kind = 0;          // 1: f32 messages of an f64 sum, 2: f64, 3: u32
+    int val_min = -1;          // which neutral value the pad slots of VAL currently hold (0: zero, 1: INF)
 };
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTARTQ, pb->G, pb->work, pb->VAL};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -405,19 +469,25 @@ int gt_pb_build(gt_graph *g) {
     PB_MALLOC(pb->cv0, (uint64_t)nchunks * 4); PB_MALLOC(pb->cv1, (uint64_t)nchunks * 4); PB_MALLOC(pb->ccol0, (uint64_t)nchunks * 4);
     k_fill_chunks<<<grid_for(nwin), TPB, 0, s>>>(g->JA, ncols, nwin, ch, cbase.as<uint32_t>(), ce0.as<uint32_t>(), ce1.as<uint32_t>(), pb->ccol0);
 
-    // v-order: entries sorted by (chunk, bin); the radix sort is stable, so (col,row) order survives inside a run
-    DevBuf key, key2, idx, idx2;
-    PB_ALLOC(key, (uint64_t)nnz * 4); PB_ALLOC(key2, (uint64_t)nnz * 4); PB_ALLOC(idx, (uint64_t)nnz * 4); PB_ALLOC(idx2, (uint64_t)nnz * 4);
-    k_keys<<<nchunks, TPB, 0, s>>>(ce0.as<uint32_t>(), ce1.as<uint32_t>(), g->IA, binbits, key.as<uint32_t>(), idx.as<uint32_t>());
-    hipcub::DoubleBuffer<uint32_t> dk(key.as<uint32_t>(), key2.as<uint32_t>()), di(idx.as<uint32_t>(), idx2.as<uint32_t>());
+    // v-order: entries sorted by (chunk, bin, row); the radix sort is stable, so inside a run rows ascend and,
+    // for equal rows, the column-major input order (ascending column) survives
+    DevBuf key, key2, idx, idx2, rkey, sidb;
+    PB_ALLOC(key, (uint64_t)nnz * 8); PB_ALLOC(key2, (uint64_t)nnz * 8); PB_ALLOC(idx, (uint64_t)nnz * 4); PB_ALLOC(idx2, (uint64_t)nnz * 4);
+    k_keys<<<nchunks, TPB, 0, s>>>(ce0.as<uint32_t>(), ce1.as<uint32_t>(), g->IA, binbits, key.as<uint64_t>(), idx.as<uint32_t>());
+    hipcub::DoubleBuffer<uint64_t> dk(key.as<uint64_t>(), key2.as<uint64_t>());
+    hipcub::DoubleBuffer<uint32_t> di(idx.as<uint32_t>(), idx2.as<uint32_t>());
     {
         size_t tb = 0;
-        PB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, di, nnz, 0, binbits + chunkbits, s));
+        PB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, di, nnz, 0, RB + binbits + chunkbits, s));
         DevBuf st; PB_ALLOC(st, tb);
-        PB_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, di, nnz, 0, binbits + chunkbits, s));
+        PB_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, di, nnz, 0, RB + binbits + chunkbits, s));
         PB_HIP(hipStreamSynchronize(s));
     }
-    uint32_t *skey = dk.Current(), *sidx = di.Current(), *head = dk.Alternate(), *sid = di.Alternate();
+    const uint64_t *skey64 = dk.Current();
+    uint32_t *sidx = di.Current(), *head = di.Alternate();
+    PB_ALLOC(rkey, (uint64_t)nnz * 4); PB_ALLOC(sidb, (uint64_t)nnz * 4);
+    uint32_t *skey = rkey.as<uint32_t>(), *sid = sidb.as<uint32_t>();
+    k_run_keys<<<grid_for(nnz), TPB, 0, s>>>(skey64, nnz, skey);
     k_heads<<<grid_for(nnz), TPB, 0, s>>>(skey, nnz, head);
     {
         size_t tb = 0;
@@ -451,6 +521,13 @@ int gt_pb_build(gt_graph *g) {
                 pb->nbins, nchunks, nrun, (double)nnz / nrun);
         for (int b = 0; b < 33; b++) if (cnt[b]) fprintf(stderr, "[pb] run length [%u,%u): %10llu runs, %5.2f%% of entries\n", 1u << b, 1u << (b + 1), (unsigned long long)cnt[b], 100.0 * hist[b] / nnz);
     }
+    // (quad, row) groups: E marks the last entry of each group in the padded v-order, X = exclusive scan of E
+    DevBuf Eb, Xb, noutpad;
+    PB_ALLOC(Eb, ((uint64_t)np + 1) * 4); PB_ALLOC(Xb, ((uint64_t)np + 1) * 4); PB_ALLOC(noutpad, (uint64_t)(nrun + 1) * 4);
+    PB_HIP(hipMemsetAsync(Eb.p, 0, ((uint64_t)np + 1) * 4, s));
+    k_group_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), Eb.as<uint32_t>());
+    PB_SCAN_EXCL(Eb.as<uint32_t>(), Xb.as<uint32_t>(), (uint64_t)np + 1);
+    k_run_outputs<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, noutpad.as<uint32_t>());
     // k-order: runs by (bin, chunk) -- stable sort of the (chunk, bin)-ordered run list by bin
     k_iota<<<grid_for(nrun), TPB, 0, s>>>(iota.as<uint32_t>(), nrun);
     {
@@ -461,27 +538,33 @@ int gt_pb_build(gt_graph *g) {
         PB_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, runbin.as<const uint32_t>(), runbin_s.as<uint32_t>(),
                                                   iota.as<const uint32_t>(), order.as<uint32_t>(), nrun, 0, binbits, s));
     }
-    k_gather_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), lenpad.as<uint32_t>(), nrun, lenpad_s.as<uint32_t>());
-    PB_SCAN_EXCL(lenpad_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun);
+    k_gather_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), noutpad.as<uint32_t>(), nrun, lenpad_s.as<uint32_t>());
+    PB_HIP(hipMemsetAsync(lenpad_s.as<uint32_t>() + nrun, 0, 4, s));
+    PB_SCAN_EXCL(lenpad_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun + 1);   // kscan[nrun] = padded outputs
+    uint32_t nout = 0;
+    PB_HIP(hipMemcpy(&nout, kscan.as<uint32_t>() + nrun, 4, hipMemcpyDeviceToHost));
+    pb->nout = nout;
+    if (getenv("GRAPHTAP_PB_STATS"))
+        fprintf(stderr, "[pb] value-stream slots after pre-aggregation: %u for %u entries (factor %.3f)\n", nout, nnz, (double)nnz / nout);
     k_scatter_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), kscan.as<uint32_t>(), nrun, pkstart.as<uint32_t>());
     DevBuf binoff; PB_ALLOC(binoff, (uint64_t)(pb->nbins + 1) * 4);
-    k_bin_offsets<<<grid_for(pb->nbins + 1), TPB, 0, s>>>(runbin_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun, np, pb->nbins, binoff.as<uint32_t>());
+    k_bin_offsets<<<grid_for(pb->nbins + 1), TPB, 0, s>>>(runbin_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun, nout, pb->nbins, binoff.as<uint32_t>());
     k_chunk_ranges<<<grid_for(nchunks), TPB, 0, s>>>(runkey.as<uint32_t>(), nrun, binbits, pvstart.as<uint32_t>(), nchunks, pb->cv0, pb->cv1);
 
-    // static streams (padded): pads read LDS slot PADCOL (the neutral message) and add it to row 0 of the bin
+    // static streams: v-order pads read LDS slot PADCOL (the neutral message); k-order pads target row 0 of the bin
     const uint64_t ngroups = ((uint64_t)np + 255) / 256;
-    PB_MALLOC(pb->LCOL, (uint64_t)np * 2); PB_MALLOC(pb->LROW, (uint64_t)np * 2);
+    PB_MALLOC(pb->LCOL, (uint64_t)np * 2); PB_MALLOC(pb->LROW, (uint64_t)std::max(nout, 4u) * 2);
     PB_MALLOC(pb->G, ngroups * sizeof(GroupRec));
-    PB_MALLOC(pb->KSTARTQ, (uint64_t)(nrun + 64) * 4);
+    PB_MALLOC(pb->KSTART, (uint64_t)(nrun + 64) * 4);
     k_fill_t<uint16_t><<<grid_for(np), TPB, 0, s>>>(pb->LCOL, np, PADCOL);
-    PB_HIP(hipMemsetAsync(pb->LROW, 0, (uint64_t)np * 2, s));
+    PB_HIP(hipMemsetAsync(pb->LROW, 0, (uint64_t)std::max(nout, 4u) * 2, s));
     if (g->A) { PB_MALLOC(pb->WT, (uint64_t)np * 4); PB_HIP(hipMemsetAsync(pb->WT, 0, (uint64_t)np * 4, s)); }
-    k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey, sidx, sid, nnz, binbits, pb->ccol0, g->IA, g->JI, g->A, vstart.as<uint32_t>(),
-                                                   pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), pb->LCOL, pb->LROW, pb->WT);
-    k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
-    PB_HIP(hipMemsetAsync(pb->KSTARTQ, 0, (uint64_t)(nrun + 64) * 4, s));
-    PB_HIP(hipMemcpyAsync(pb->KSTARTQ, pkstart.p, (uint64_t)nrun * 4, hipMemcpyDeviceToDevice, s));
-    k_shr2<<<grid_for(nrun), TPB, 0, s>>>(pb->KSTARTQ, nrun);
+    k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey64, sidx, sid, nnz, binbits, pb->ccol0, g->JI, g->A, vstart.as<uint32_t>(),
+                                                   pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Eb.as<uint32_t>(), Xb.as<uint32_t>(),
+                                                   pb->LCOL, pb->LROW, pb->WT);
+    k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
+    PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nrun + 64) * 4, s));
+    PB_HIP(hipMemcpyAsync(pb->KSTART, pkstart.p, (uint64_t)nrun * 4, hipMemcpyDeviceToDevice, s));
     // phase-2 work list (host: nbins is small)
     std::vector<uint32_t> hoff(pb->nbins + 1);
     PB_HIP(hipMemcpyAsync(hoff.data(), binoff.p, (uint64_t)(pb->nbins + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -506,9 +589,13 @@ int gt_pb_build(gt_graph *g) {
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s) {
+    if (pb->val_min != (IS_MIN ? 1 : 0)) {   // the pad slots of the k-order hold the semiring's neutral value
+        k_fill_t<TV><<<grid_for(pb->nout), TPB, 0, s>>>((TV *)pb->VAL, pb->nout, IS_MIN ? (TV)GT_INF : (TV)0);
+        pb->val_min = IS_MIN ? 1 : 0;
+    }
     k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<pb->nchunks, P1_THREADS, 0, s>>>(
-        pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTARTQ,
-        (const GroupRec *)pb->G, x, (V4<TV> *)pb->VAL);
+        pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
+        (const GroupRec *)pb->G, x, (TV *)pb->VAL);
     k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y);
     GT_HIP(hipGetLastError());
     return GT_OK;
@@ -518,12 +605,16 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
+    // one value stream per graph (SpMVs of one graph must not overlap in time); its element type follows the SpMV
     const uint32_t need = (semiring == GT_PLUS_F64 && !f32_messages) ? 8 : 4;
-    if (pb->val_bytes < need) {  // one value stream per graph: SpMVs of one graph must not overlap in time
-        if (pb->VAL) GT_HIP(hipFree(pb->VAL));
-        pb->VAL = nullptr; pb->val_bytes = 0;
-        GT_HIP(hipMalloc(&pb->VAL, (uint64_t)pb->np * need));
-        pb->val_bytes = need;
+    const int kind = (semiring == GT_PLUS_F64) ? (f32_messages ? 1 : 2) : 3;
+    if (pb->val_bytes != need || pb->val_kind != kind) {
+        if (pb->val_bytes < need) {
+            if (pb->VAL) GT_HIP(hipFree(pb->VAL));
+            pb->VAL = nullptr; pb->val_bytes = 0;
+            GT_HIP(hipMalloc(&pb->VAL, (uint64_t)std::max(pb->nout, 4u) * need));
+        }
+        pb->val_bytes = need; pb->val_kind = kind; pb->val_min = -1;   // pads must be re-filled for the new element type
     }
     switch (semiring) {
         case GT_PLUS_F64:
