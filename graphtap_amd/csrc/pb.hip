@@ -291,10 +291,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const uint32_t e0 = live && (lc[u].c[0] & GEND), e1 = live && (lc[u].c[1] & GEND), e2 = live && (lc[u].c[2] & GEND),
                            e3 = live && (lc[u].c[3] & GEND);
             const uint32_t n = e0 + e1 + e2 + e3;
-            uint32_t p = n;   // inclusive prefix of n over the wave
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(p, d); if (lane >= (uint32_t)d) p += t; }
-            const uint32_t pex = p - n;
+            // exclusive prefix of n over the wave without touching the LDS pipe: one ballot + mbcnt per group-end bit
+            auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
+            const uint32_t pex = below(__ballot(e0)) + below(__ballot(e1)) + below(__ballot(e2)) + below(__ballot(e3));
+            const uint32_t p = pex + n;   // inclusive
             // segmented combine over the quad: one output per (quad, row) group, compacted into the wave's LDS
             // staging row at [pex, pex + n) so that the stores below are fully coalesced
             TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
