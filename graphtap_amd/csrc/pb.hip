@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t NW = P1_THREADS / 64;
-    constexpr int U = 2;   // 256-entry groups in flight per wave
+    constexpr int U = 4;   // 256-entry groups in flight per wave
     const uint32_t gend = (q1c + 63) >> 6;
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
     // Groups are aligned to 64 quads in v-space; a group at a chunk border is visited by both chunks,
