@@ -454,3 +454,81 @@ def test_pagerank_f32_message_variant_within_tolerance(gt, O, scale, seed, monke
     rel = np.abs(r["rank"] - ref["rank"]) / ref["rank"]
     print("f32-message PageRank scale %d: max rel err %.3g" % (scale, rel.max()))
     assert rel.max() < PR_RTOL
+
+
+# ------------------------------------------------------------------------------- randomized graphs
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs_all_programs_against_oracle(gt, O, seed):
+    """Small random graphs of varied shape (isolated ids, dense hubs, duplicates, self loops, a path, ids up to
+    N itself), every program end to end against the oracle; sizes cross the PB structure boundaries (more than
+    one 8192-column window, more than one 16384-row bin on the larger draws)."""
+    rng = np.random.RandomState(1000 + seed)
+    nv = int(rng.choice([7, 64, 1000, 20000, 40000]))
+    m = int(rng.choice([1, 5, 300, 5000, 200000]))
+    kind = seed % 4
+    if kind == 0:      # uniform
+        e = rng.randint(0, nv + 1, size=(m, 2))
+    elif kind == 1:    # hubs: a few vertices take most endpoints
+        hubs = rng.randint(0, nv + 1, size=4)
+        e = rng.randint(0, nv + 1, size=(m, 2))
+        mask = rng.rand(m) < 0.6
+        e[mask, rng.randint(0, 2)] = hubs[rng.randint(0, 4, size=mask.sum())]
+    elif kind == 2:    # many duplicates and self loops
+        e = rng.randint(0, min(nv, 30) + 1, size=(m, 2))
+    else:              # a long path plus noise
+        k = min(m, nv)
+        path = np.stack([np.arange(k), np.arange(1, k + 1)], axis=1)
+        e = np.concatenate([path, rng.randint(0, nv + 1, size=(max(m - k, 1), 2))])
+    e = np.ascontiguousarray(e, dtype=np.uint32)
+    w = np.concatenate([e, rng.randint(1, 129, size=(len(e), 1)).astype(np.uint32)], axis=1)
+    root = int(e[0, 0])
+    ref = O.run_app("pr", e, nv, iters=5); r = run_pr(gt, e, nv, 5)
+    assert (r["degree"] == ref["degree"]).all() and np.allclose(r["rank"], ref["rank"], rtol=PR_RTOL, atol=0)
+    ref = O.run_app("pr", e, nv, iters=0, cf=False); r = run_pr(gt, e, nv, 0, cf=False)
+    assert r["iterations"] == ref["iterations"] and np.allclose(r["rank"], ref["rank"], rtol=PR_RTOL, atol=0)
+    ref = O.run_app("bfs", e, nv, root=root); r = run_min(gt, "bfs", e, nv, root)
+    assert (r["parent"] == ref["parent"]).all() and (r["hops"] == ref["hops"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("cc", e, nv); r = run_min(gt, "cc", e, nv)
+    assert (r["label"] == ref["label"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("sssp", w, nv, root=root); r = run_min(gt, "sssp", w, nv, root)
+    assert (r["distance"] == ref["distance"]).all() and r["iterations"] == ref["iterations"]
+    G = gt.Graph(); G.load_edges(e, nv, nv, True, False, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._ROW_); V.execute(1)
+    assert (V.V["degree"] == O.run_app("deg", e, nv)["degree"]).all()
+    V.free(); G.free()
+
+
+def test_bfs_cc_sssp_properties_at_rmat20(gt):
+    """Size-independent properties (R-MAT 20 symmetrised: ~32 M stored entries), checked on
+    the host against the edge list itself: BFS parent/hops consistency (parent is a neighbour one level up, the
+    minimum such id), CC labels constant along every edge and equal to a member id, SSSP distances satisfy the
+    triangle inequality on every edge with equality on at least one incoming edge of every reached vertex."""
+    from graphtap_amd.rmat import rmat_edges
+    scale, nv = 20, 1 << 20   # host-side checks stay in seconds at scale 20; the GPU path is the same code as at 22/26
+    w = rmat_edges(scale, 16, 7, weighted=True); e = np.ascontiguousarray(w[:, :2])
+    root = 0
+    r = run_min(gt, "bfs", e, nv, root)
+    hops, parent = r["hops"].astype(np.int64), r["parent"].astype(np.int64)
+    INF = gt.INF
+    a = np.concatenate([e[:, 0], e[:, 1]]).astype(np.int64); b = np.concatenate([e[:, 1], e[:, 0]]).astype(np.int64)
+    keep = a != b; a, b = a[keep], b[keep]                      # symmetrised, no self loops (bfs.cpp:26-30)
+    reached = hops != INF
+    assert hops[root] == 0 and parent[root] == root
+    assert (np.abs(hops[a] - hops[b])[reached[a] & reached[b]] <= 1).all() and (reached[a] == reached[b]).all()
+    # parent[v] = min id among neighbours at level hops[v]-1
+    cand = np.full(nv + 2, INF, np.int64)
+    up = reached[b] & reached[a] & (hops[a] + 1 == hops[b])
+    np.minimum.at(cand, b[up], a[up])
+    chk = reached & (np.arange(nv + 2) != root)
+    assert (parent[chk] == cand[chk]).all()
+    r = run_min(gt, "cc", e, nv)
+    lab = r["label"].astype(np.int64)
+    assert (lab[a] == lab[b]).all() and (lab[lab[:nv + 1]] == lab[:nv + 1]).all() and (lab[:nv + 1] <= np.arange(nv + 1)).all()
+    r = run_min(gt, "sssp", w, nv, root)
+    d = r["distance"].astype(np.int64)
+    src, dst, ww = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64), w[:, 2].astype(np.int64)
+    ok = (src != dst) & (d[src] != INF)
+    assert (d[dst][ok] <= d[src][ok] + ww[ok]).all()
+    best = np.full(nv + 2, INF, np.int64); np.minimum.at(best, dst[ok], d[src][ok] + ww[ok])
+    reach = (d != INF) & (np.arange(nv + 2) != root)
+    assert (d[reach] == best[reach]).all() and d[root] == 0
