@@ -3,6 +3,7 @@
 // Replaces Vertex_Program<> (src/vp/vertex_program.hpp): state vectors V / C live in HBM as
 // struct-of-arrays over the owned vertex segment; messenger (K7/K8), applicator (K10/K11) and
 // the convergence count (K12) are kernels; the five apps' hooks (src/apps/*.h) are op-codes.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -62,6 +63,7 @@ struct gt_program {
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
     bool timing = false;
+    uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
     bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
 };
 
@@ -415,7 +417,8 @@ static int init_common(gt_program *p) {
     const gt_graph *g = p->g;
     const uint32_t H = g->info.tile_height, base = g->info.rank * H;
     hipStream_t s = p->stream;
-    p->iteration = 0; p->converged = false;
+    static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
+    p->iteration = 0; p->converged = false; p->init_epoch = ++epoch_counter;
     switch (p->prm.kind) {
         case GT_DEG:  // deg.h:31-34
             GT_HIP(hipMemsetAsync(p->s0, 0, (uint64_t)H * 4, s));
@@ -535,7 +538,7 @@ static int combine_impl(gt_program *p, bool timed) {
         e0 = p->ev[p->ev_used]; e1 = p->ev[p->ev_used + 1]; p->ev_used += 2;
         GT_HIP(hipEventRecord(e0, s));
     }
-    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32);
+    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch);
     if (st != GT_OK) return st;
     if (timed) GT_HIP(hipEventRecord(e1, s));
     return GT_OK;

@@ -49,10 +49,14 @@ struct gt_graph {
 // pb.hip
 int gt_pb_build(gt_graph *g);
 void gt_pb_free(struct gt_pb *pb);
-int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32);
+int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
+               const void *owner, uint64_t epoch);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
 // kernels.hip
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
-int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false);
+// owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
+// min programs skip chunks without an active column (activity filtering)
+int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
+                   const void *owner = nullptr, uint64_t epoch = 0);

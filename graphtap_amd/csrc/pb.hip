@@ -81,7 +81,7 @@ struct DevBuf {
 };
 
 struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes, k-slots in output units
-struct BinWork { uint32_t bin, k0, k1, single; };
+struct BinWork { uint32_t bin, k0, k1, single, c_lo, c_hi, pad0, pad1; };   // [c_lo, c_hi]: chunks whose runs overlap [k0, k1)
 
 // ------------------------------------------------------------------ build kernels
 __global__ void k_win_counts(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t nwin, uint32_t ch, uint32_t *__restrict__ nsub) {
@@ -218,6 +218,47 @@ __global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32
     }
 }
 
+// chunk range of every phase-2 work item: runs are sorted by (bin, chunk) in the k-order, kscan = their k-starts
+__global__ void k_work_chunks(BinWork *__restrict__ work, uint32_t nwork, const uint32_t *__restrict__ kscan, const uint32_t *__restrict__ order,
+                              const uint32_t *__restrict__ runkey, uint32_t nrun, int binbits) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += gridDim.x * blockDim.x) {
+        BinWork w = work[i];
+        // last run starting at or before k: upper_bound - 1
+        auto run_at = [&](uint32_t k) -> uint32_t {
+            uint32_t lo = 0, hi = nrun;
+            while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (kscan[mid] <= k) lo = mid + 1; else hi = mid; }
+            return lo - 1;
+        };
+        w.c_lo = runkey[order[run_at(w.k0)]] >> binbits;
+        w.c_hi = runkey[order[run_at(w.k1 - 1)]] >> binbits;
+        work[i] = w;
+    }
+}
+// inclusive prefix of the per-chunk activity flags written by phase 1 (one block; nchunks is a few thousand)
+__global__ void k_active_prefix(const uint32_t *__restrict__ active, uint32_t nchunks, uint32_t *__restrict__ prefix) {
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) { carry = 0; prefix[0] = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < nchunks; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v = (i < nchunks) ? active[i] : 0;
+        // block-wide inclusive scan through LDS (simple Hillis-Steele on 1024 threads)
+        __shared__ uint32_t buf[1024];
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+            uint32_t t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nchunks) prefix[i + 1] = carry + buf[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry += buf[threadIdx.x];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ phase 1
 // T  = type of y and of the LDS accumulators (double or uint32_t)
 // TV = type of the value stream VAL and of the LDS message window: T, or float for the
@@ -237,7 +278,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nquads,
                                                            const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
-                                                           const TX *__restrict__ x, TV *__restrict__ VAL) {
+                                                           const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active) {
     __shared__ TV xwin[W + 64];
     __shared__ TV stage[P1_THREADS / 64][256];   // per-wave compaction row for the outputs of one 256-entry group
     const uint32_t c = blockIdx.x;
@@ -252,6 +293,21 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #pragma unroll
         for (int i = 0; i < PER; i++) xwin[threadIdx.x + i * P1_THREADS] = (TV)t[i];
         if (threadIdx.x == 0) xwin[PADCOL] = neutral;
+        if constexpr (IS_MIN) {
+            // Activity filtering (the reference's sparse path, vp:754-784, 1475-1489, at window granularity): a chunk
+            // whose window holds no active column (every message is infinity()) produces only neutral values. With
+            // chunk_active != nullptr the caller guarantees that VAL already holds, in this chunk's slots, either
+            // the neutral value or messages of an earlier iteration of the SAME program -- harmless to re-combine
+            // because y is a running min (vp:1785) -- so the chunk is skipped entirely.
+            if (chunk_active) {
+                int any = 0;
+#pragma unroll
+                for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; any |= (j < wn && t[i] != (TX)GT_INF); }
+                any = __syncthreads_or(any);
+                if (threadIdx.x == 0) chunk_active[c] = any ? 1u : 0u;
+                if (!any) return;
+            }
+        }
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
@@ -350,9 +406,11 @@ template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *a
 
 template <class T, class TV, bool IS_MIN>
 __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restrict__ work, const C4 *__restrict__ LROW4,
-                                                          const V4<TV> *__restrict__ VAL4, uint32_t nrows, T *__restrict__ y) {
+                                                          const V4<TV> *__restrict__ VAL4, uint32_t nrows, T *__restrict__ y,
+                                                          const uint32_t *__restrict__ active_prefix) {
     __shared__ T acc[R];
     const BinWork wk = work[blockIdx.x];
+    if (active_prefix && active_prefix[wk.c_hi + 1] == active_prefix[wk.c_lo]) return;   // no active chunk feeds this slice
     const T neutral = IS_MIN ? (T)GT_INF : (T)0;
     for (uint32_t i = threadIdx.x; i < R; i += P2_THREADS) acc[i] = neutral;
     __syncthreads();
@@ -403,13 +461,16 @@ struct gt_pb {
     BinWork *work = nullptr;
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
+    uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
+    const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
+    uint64_t val_epoch = 0;
     int val_kind = 0;          // 1: f32 messages of an f64 sum, 2: f64, 3: u32
     int val_min = -1;          // which neutral value the pad slots of VAL currently hold (0: zero, 1: INF)
 };
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -577,31 +638,42 @@ int gt_pb_build(gt_graph *g) {
         uint32_t parts = (uint32_t)((n + EPW - 1) / EPW);
         for (uint32_t i = 0; i < parts; i++) {
             uint64_t a = hoff[b] + (uint64_t)i * EPW, e = std::min<uint64_t>(a + EPW, hoff[b + 1]);
-            work.push_back(BinWork{b, (uint32_t)a, (uint32_t)e, parts == 1 ? 1u : 0u});
+            work.push_back(BinWork{b, (uint32_t)a, (uint32_t)e, parts == 1 ? 1u : 0u, 0u, 0u, 0u, 0u});
         }
     }
     pb->nwork = (uint32_t)work.size();
     PB_MALLOC(pb->work, work.size() * sizeof(BinWork));
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
+    if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
+    PB_MALLOC(pb->chunk_active, (uint64_t)nchunks * 4); PB_MALLOC(pb->active_prefix, (uint64_t)(nchunks + 1) * 4);
+    PB_HIP(hipStreamSynchronize(s));
+    PB_HIP(hipGetLastError());
     g->pb = pb;
     return GT_OK;
 }
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
-static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s) {
-    if (pb->val_min != (IS_MIN ? 1 : 0)) {   // the pad slots of the k-order hold the semiring's neutral value
+static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch) {
+    // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see k_pb_scatter).
+    bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
+    if (filter && (pb->val_owner != owner || pb->val_epoch != epoch)) { pb->val_min = -1; pb->val_owner = owner; pb->val_epoch = epoch; }
+    if (!filter) pb->val_owner = nullptr;
+    if (pb->val_min != (IS_MIN ? 1 : 0)) {   // pad slots (and, with filtering, every slot) start at the semiring's neutral value
         k_fill_t<TV><<<grid_for(pb->nout), TPB, 0, s>>>((TV *)pb->VAL, pb->nout, IS_MIN ? (TV)GT_INF : (TV)0);
         pb->val_min = IS_MIN ? 1 : 0;
     }
     k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<pb->nchunks, P1_THREADS, 0, s>>>(
         pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
-        (const GroupRec *)pb->G, x, (TV *)pb->VAL);
-    k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y);
+        (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr);
+    if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
+    k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
+                                                                filter ? pb->active_prefix : nullptr);
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
-int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32) {
+int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
+               const void *owner, uint64_t epoch) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -614,19 +686,19 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
             pb->VAL = nullptr; pb->val_bytes = 0;
             GT_HIP(hipMalloc(&pb->VAL, (uint64_t)std::max(pb->nout, 4u) * need));
         }
-        pb->val_bytes = need; pb->val_kind = kind; pb->val_min = -1;   // pads must be re-filled for the new element type
+        pb->val_bytes = need; pb->val_kind = kind; pb->val_min = -1; pb->val_owner = nullptr;   // re-fill for the new element type
     }
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }
