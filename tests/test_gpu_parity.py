@@ -532,3 +532,48 @@ def test_bfs_cc_sssp_properties_at_rmat20(gt):
     best = np.full(nv + 2, INF, np.int64); np.minimum.at(best, dst[ok], d[src][ok] + ww[ok])
     reach = (d != INF) & (np.arange(nv + 2) != root)
     assert (d[reach] == best[reach]).all() and d[root] == 0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pr1_flow_two_graphs(gt, name, known_answers):
+    """apps/pr1.cpp: Degree in _ROW_ order on the UNtransposed graph, then PageRank on a second, transposed
+    graph initialised from it (plain TCSC) -- initialize(other) across two graph objects."""
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, False, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._ROW_); V.execute(1)
+    GR = gt.Graph(); GR.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    VR = gt.PR_Program(GR, True, False, False, gt._ROW_); VR.initialize(V)
+    VR.execute(20)
+    st = VR.V
+    assert (st["degree"][:n] == c["np1_pr1app20_a"]).all()
+    ref = c["np1_pr1app20_c"]
+    assert (np.abs(st["rank"][:n] - ref) / ref).max() < PR_RTOL
+    ka = known_answers[name]["np1_pr1app20"]
+    assert VR.checksum(out=None)[1] == ka["reachable"]
+    VR.free(); V.free(); GR.free(); G.free()
+
+
+def test_api_misuse_is_reported_not_fatal(gt):
+    L = gt._lib.lib()
+    c = load_case("rmat8")
+    # SSSP on an unweighted graph (the reference would need a different binary: -DHAS_WEIGHT)
+    G = gt.Graph(); G.load_edges(c["edges"], 256, 256, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.SSSP_Program(G, False, True, False, gt._ROW_)
+    with pytest.raises(gt.GraphTapError, match="weighted"):
+        P.execute()
+    # _COL_ ordering exists for Degree only (the reference: "Not implemented", vp:1319-1322)
+    P2 = gt.PR_Program(G, True, False, False, gt._COL_)
+    with pytest.raises(gt.GraphTapError, match="_COL_"):
+        P2.execute(1)
+    # stationary flag must match the program (apps/*.cpp)
+    with pytest.raises(gt.GraphTapError, match="stationary"):
+        gt.BFS_Program(G, True, False, True, gt._ROW_)
+    # switching a graph away from the f32-message variant under a live PageRank program is refused, not miscomputed
+    gt._lib.check(L.gt_graph_select_spmv(G._h, gt._lib.GT_SPMV_PB_F32MSG))
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V)
+    gt._lib.check(L.gt_graph_select_spmv(G._h, gt._lib.GT_SPMV_EDGE))
+    with pytest.raises(gt.GraphTapError, match="f32 message"):
+        VR.execute(2)
+    assert L.gt_graph_select_spmv(G._h, 7) != 0 and b"variant" in L.gt_last_error()
+    VR.free(); V.free(); G.free()
