@@ -82,11 +82,11 @@ __global__ void k_msg_pr(TX *__restrict__ x, const uint32_t *__restrict__ JC, ui
     }
 }
 __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
-                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, int kind) {
+                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
         // bfs.h:52-54 (vid), sssp.h:44-46 (distance), cc.h:38-40 (label); inactive -> infinity() vp:749-750
-        x[j] = C[v] ? (kind == GT_BFS ? vid_base + v : s0[v]) : GT_INF;
+        x[j] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
     }
 }
 
@@ -196,10 +196,10 @@ template <class T> __global__ void k_fill(T *__restrict__ p, uint64_t n, T v) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 // initializer(vid, state): bfs.h:37-50, sssp.h:33-42, cc.h:33-36
-__global__ void k_init_min(int kind, uint32_t H, uint32_t vid_base, uint32_t root, uint32_t *__restrict__ s0,
+__global__ void k_init_min(int kind, uint32_t H, uint32_t vid_base, gt_vidmap vm, uint32_t root, uint32_t *__restrict__ s0,
                            uint32_t *__restrict__ s1, uint8_t *__restrict__ C) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x) {
-        uint32_t vid = vid_base + i;
+        const uint32_t vid = gt_vid_of(vm, (uint64_t)vid_base + i);   // ~0u for padding slots: never equals a root, never a label that wins
         if (kind == GT_BFS) { s0[i] = (vid == root) ? vid : 0; s1[i] = (vid == root) ? 0 : GT_INF; C[i] = (vid == root); }
         else if (kind == GT_SSSP) { s0[i] = (vid == root) ? 0 : GT_INF; C[i] = (vid == root); }
         else { s0[i] = vid; C[i] = 1; }
@@ -289,7 +289,20 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     g->info.num_vertices = num_vertices;
     g->info.nrows = num_vertices + 1;                          // mat/graph.hpp:89-90
     g->info.nranks = (uint32_t)nranks; g->info.rank = (uint32_t)rank;
-    g->info.tile_height = g->info.nrows / (uint32_t)nranks + 1;  // mat/matrix.hpp:193
+    // One rank: the reference's id space as is. Several ranks: contiguous id ranges of an R-MAT (or any
+    // degree-skewed) graph are badly unbalanced -- tile-row 0 of 8 holds 44 % of R-MAT-26 -- so ranks own
+    // contiguous ranges of a multiplicatively hashed INTERNAL id space (a bijection on the next power of
+    // two; results are reported in original ids, see gt_graph_vertex_ids).
+    g->nint = g->info.nrows;
+    if (nranks > 1) {
+        uint32_t M = 1; while (M < g->info.nrows && M < 0x80000000u) M <<= 1;
+        GT_REQUIRE(M >= g->info.nrows, GT_ERR_UNSUPPORTED, "more than 2^31 vertices on several ranks");
+        g->perm_a = 0x9E3779B1u; g->perm_mask = M - 1; g->nint = M;
+        uint32_t inv = g->perm_a;   // Newton: inverse of an odd number modulo 2^32
+        for (int it = 0; it < 5; it++) inv *= 2u - g->perm_a * inv;
+        g->perm_ainv = inv;
+    }
+    g->info.tile_height = g->nint / (uint32_t)nranks + 1;  // mat/matrix.hpp:193, over the (internal) id space
     g->info.weighted = weighted ? 1 : 0;
     const void *dev_edges = edges;
     void *staged = nullptr;
@@ -326,6 +339,14 @@ int gt_graph_select_spmv(gt_graph *g, int variant) {
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info) {
     GT_REQUIRE(g && info, GT_ERR_INVALID, "null argument");
     *info = g->info;
+    return GT_OK;
+}
+int gt_graph_vertex_ids(const gt_graph *g, uint32_t *host_out, uint64_t count) {
+    GT_REQUIRE(g && host_out, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(count <= g->info.tile_height, GT_ERR_INVALID, "count exceeds tile_height");
+    const gt_vidmap vm = gt_vidmap_of(g);
+    const uint64_t base = (uint64_t)g->info.rank * g->info.tile_height;
+    for (uint64_t i = 0; i < count; i++) { const uint32_t v = gt_vid_of(vm, base + i); host_out[i] = v < g->info.nrows ? v : 0xFFFFFFFFu; }
     return GT_OK;
 }
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *a) {
@@ -430,7 +451,7 @@ static int init_common(gt_program *p) {
             GT_HIP(hipMemsetAsync(p->C, 1, H, s));
             break;
         default:
-            k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, p->prm.root, p->s0, p->s1, p->C);
+            k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
             break;
     }
     // messages: padding columns are never referenced; give them the semiring's neutral message
@@ -510,7 +531,7 @@ int gt_program_scatter_gather(gt_program *p) {
         }
         default:
             k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, g->JC, nc, p->C, p->s0,
-                                                   g->info.rank * g->info.tile_height, p->prm.kind);
+                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
             break;
     }
     GT_HIP(hipGetLastError());
@@ -685,6 +706,7 @@ int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable)
     const gt_graph_info &i = p->g->info;
     const uint32_t H = i.tile_height;
     const uint64_t base = (uint64_t)i.rank * H;
+    const gt_vidmap vm = gt_vidmap_of(p->g);
     uint64_t s = 0, c = 0;
     { int st = pr_sync_state(p); if (st != GT_OK) return st; }
     GT_HIP(hipStreamSynchronize(p->stream));
@@ -692,14 +714,14 @@ int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable)
         std::vector<double> h(H);
         GT_HIP(hipMemcpy(h.data(), p->rank, (uint64_t)H * 8, hipMemcpyDeviceToHost));
         for (uint32_t v = 0; v < H; v++)
-            if (h[v] != 0.0 && base + v < i.nrows) { s = (uint64_t)((double)s + h[v]); c++; }
+            if (h[v] != 0.0 && gt_vid_of(vm, base + v) < i.nrows) { s = (uint64_t)((double)s + h[v]); c++; }
     } else {
         const uint32_t inf = (p->prm.kind == GT_DEG) ? 0u : GT_INF;
         const uint32_t *src = (p->prm.kind == GT_BFS) ? p->s1 : p->s0;  // BFS get_state() = hops (bfs.h:27)
         std::vector<uint32_t> h(H);
         GT_HIP(hipMemcpy(h.data(), src, (uint64_t)H * 4, hipMemcpyDeviceToHost));
         for (uint32_t v = 0; v < H; v++)
-            if (h[v] != inf && base + v < i.nrows) { s += h[v]; c++; }
+            if (h[v] != inf && gt_vid_of(vm, base + v) < i.nrows) { s += h[v]; c++; }
     }
     *value_sum = s; *reachable = c;
     return GT_OK;

@@ -42,6 +42,9 @@ struct gt_graph {
     uint32_t *JV = nullptr;   // [H] local vertex -> compressed col
     uint32_t *R2C = nullptr;  // [nnzrows] compressed row -> compressed col of the same vertex, or ~0u
     uint32_t ncols_total = 0; // nranks * seg_stride
+    // Balanced relabelling for multi-rank graphs (identity when nranks == 1): internal id = (vid * perm_a) & perm_mask,
+    // vid = (internal * perm_ainv) & perm_mask. Segments are contiguous ranges of INTERNAL ids.
+    uint32_t perm_a = 1, perm_ainv = 1, perm_mask = 0xFFFFFFFFu, nint = 0;  // nint = size of the internal id space
     struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
     int spmv_variant = 1;        // gt_spmv_variant
 };
@@ -53,6 +56,18 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
                const void *owner, uint64_t epoch);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
+
+// Original vertex id of state slot / internal id u. One rank (identity map): u itself, also for the padding slot
+// u = nrows, exactly like the reference's get_vid (vp:1805-1808). Several ranks: ~0u when u is not a vertex.
+// A slot holds a real vertex iff gt_vid_of(...) < nrows.
+struct gt_vidmap { uint32_t ainv, mask, nint, nrows; };
+__host__ __device__ inline uint32_t gt_vid_of(const gt_vidmap &m, uint64_t u) {
+    if (m.mask == 0xFFFFFFFFu) return (uint32_t)u;
+    if (u >= m.nint) return 0xFFFFFFFFu;
+    const uint32_t v = ((uint32_t)u * m.ainv) & m.mask;
+    return v < m.nrows ? v : 0xFFFFFFFFu;
+}
+inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv, g->perm_mask, g->nint, g->info.nrows}; }
 
 // kernels.hip
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);

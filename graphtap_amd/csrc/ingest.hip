@@ -36,7 +36,7 @@ struct DevBuf {  // frees on scope exit: ingest scratch
 // Order of the flag handling is the reference's (graph.hpp:337-356): drop self loop unless
 // self_loops; acyclic swap; transpose swap; insert; mirrored insert when !directed.
 __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f,
-                         uint32_t nrows, uint32_t H, uint32_t row_lo, uint32_t row_hi,
+                         uint32_t nrows, uint32_t perm_a, uint32_t perm_mask, uint32_t H, uint32_t row_lo, uint32_t row_hi,
                          uint64_t *__restrict__ keys, uint32_t *__restrict__ wts,
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
                          unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
@@ -51,6 +51,7 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
         } else if (!(row == col && !f.self_loops)) {
             if (f.acyclic && col < row) { uint32_t t = row; row = col; col = t; }
             if (f.transpose) { uint32_t t = row; row = col; col = t; }
+            row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;   // internal ids (identity on one rank)
             rowflag[row] = 1; colflag[col] = 1; glob++;
             if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; kept++; }
             if (!f.directed) {
@@ -154,7 +155,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     const uint32_t p = g->info.nranks, k = g->info.rank, H = g->info.tile_height, nrows = g->info.nrows;
     const uint64_t span = (uint64_t)p * H;             // vertex slots of the whole grid (>= nrows)
     const uint32_t row_lo = k * H;
-    const uint32_t row_hi = (uint32_t)(((uint64_t)(k + 1) * H < nrows) ? (uint64_t)(k + 1) * H : nrows);
+    const uint32_t row_hi = (uint32_t)(((uint64_t)(k + 1) * H < g->nint) ? (uint64_t)(k + 1) * H : g->nint);
     const int stride = weighted ? 3 : 2;
     const int slots = f.directed ? 1 : 2;
     const uint64_t cap = m * slots;
@@ -171,7 +172,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
 
     if (m)
-        k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, H, row_lo, row_hi,
+        k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
                                              counters.as<unsigned long long>());

@@ -114,6 +114,14 @@ class Graph:
             self.nnz_global = int(t.item())
         return self
 
+    def vertex_ids(self):
+        """Original vertex id of every state slot of this rank (0xFFFFFFFF = padding slot). Identity on one rank; on
+        several ranks the owned segment is a range of a hashed internal id space (gt_graph_vertex_ids)."""
+        H = self.info.tile_height
+        a = np.zeros(H, np.uint32)
+        check(lib().gt_graph_vertex_ids(self._h, a.ctypes.data_as(C.c_void_p), H))
+        return a
+
     def tile(self):
         t = TileArrays()
         check(lib().gt_graph_tile(self._h, C.byref(t)))

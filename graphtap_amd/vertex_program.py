@@ -178,8 +178,27 @@ class Vertex_Program:
             out[name] = a
         return out
 
-    def get_vid(self, index):   # vp:1805-1808
-        return index + self.G.info.rank * self.G.info.tile_height
+    def get_vid(self, index):   # vp:1805-1808 (one rank); several ranks: through the graph's slot -> vertex map
+        if self.G.nranks == 1:
+            return index + self.G.info.rank * self.G.info.tile_height
+        return int(self.G.vertex_ids()[index])
+
+    def gather_global(self):
+        """{field: array over original vertex ids 0..nrows-1} assembled from every rank's V (all ranks get it)."""
+        V, vids = self.V, self.G.vertex_ids()
+        keep = vids != 0xFFFFFFFF
+        n = self.G.info.nrows
+        parts = [(vids[keep], {k: v[keep] for k, v in V.items()})]
+        if self.G.nranks > 1:
+            import torch.distributed as dist
+            allp = [None] * self.G.nranks
+            dist.all_gather_object(allp, parts[0])
+            parts = allp
+        out = {name: np.zeros(n, dtype) for name, _, dtype in self.fields}
+        for ids, vals in parts:
+            for k in out:
+                out[k][ids] = vals[k]
+        return out
 
     # -- checksum(), vp:1927-1960 (the accumulator is uint64_t: an fp state truncates at every add)
     def checksum(self, out=sys.stdout):
@@ -204,9 +223,13 @@ class Vertex_Program:
 
     # -- display(count = 31), vp:2124-2181
     def display(self, count=31, out=sys.stdout):
-        V = self.V
-        count = min(count, self.G.info.tile_height)
-        lines = ["vertex[%d]:%s" % (self.get_vid(i), self.print_state(V, i)) for i in range(count)]
+        if self.G.nranks == 1:
+            V = self.V
+            count = min(count, self.G.info.tile_height)
+        else:   # the reference prints rank 0's first states (vertices 0..30 at np=1); here: vertices 0..count-1
+            V = self.gather_global()
+            count = min(count, self.G.info.nrows)
+        lines = ["vertex[%d]:%s" % (i, self.print_state(V, i)) for i in range(count)]
         if self.G.rank == 0 and out is not None:
             print("\n".join(lines), file=out)
         return lines

@@ -141,9 +141,9 @@ int gt_set_device(int device);
  * non-empty row/column filters and the TCSC build all run on the device
  * (replaces parread_binary :308-372, Matrix::init_tiles matrix.hpp:538-560,
  * init_filtering :813-858 and TCSC_BASE::populate compressed_column.hpp:371-417).
- * rank/nranks: the handle keeps tile-row `rank` of the reference's nranks x nranks
- * grid (1-D row partition, a=1 b=p of SURVEY 8e); every rank passes the SAME
- * full edge list. The caller may free `edges` after the call returns. */
+ * rank/nranks: the handle keeps tile-row `rank` of an nranks x nranks grid (1-D row
+ * partition, a=1 b=p of SURVEY 8e) laid over a hashed internal id space when
+ * nranks > 1 (see gt_graph_vertex_ids); every rank passes the SAME full edge list. The caller may free `edges` after the call returns. */
 int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
                    uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
@@ -151,6 +151,12 @@ int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
  * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
 int gt_graph_select_spmv(gt_graph *g, int variant);
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
+/* Original vertex id of the first `count` (<= tile_height) state slots of this handle, UINT32_MAX for a padding
+ * slot. On one rank slot i is vertex i (the reference's layout, vp:1805-1808). On several ranks the owned
+ * segment is a contiguous range of a hashed internal id space (load balance under degree skew: tile-row 0 of 8
+ * would hold 44 % of R-MAT-26), so callers that assemble a global V use this map; results per vertex are the
+ * same for every rank count. */
+int gt_graph_vertex_ids(const gt_graph *g, uint32_t *host_out, uint64_t count);
 /* Graph::free (mat/graph.hpp:76-81). Programs borrow the graph: free them first. */
 int gt_graph_free(gt_graph *g);
 

@@ -311,10 +311,13 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
                 break
 
     def gather(progs, field):
-        H = progs[0].G.info.tile_height
-        full = np.concatenate([p.V[field] for p in progs])
-        assert full.size == nranks * H
-        return full[:n]
+        """global array over original vertex ids from the p ranks' state slots (gt_graph_vertex_ids)"""
+        out = np.zeros(n, progs[0].V[field].dtype); seen = np.zeros(n, bool)
+        for p in progs:
+            vids = p.G.vertex_ids(); keep = vids != 0xFFFFFFFF
+            out[vids[keep]] = p.V[field][keep]; assert not seen[vids[keep]].any(); seen[vids[keep]] = True
+        assert seen.all()
+        return out
 
     # BFS
     graphs = []
@@ -577,3 +580,25 @@ def test_api_misuse_is_reported_not_fatal(gt):
         VR.execute(2)
     assert L.gt_graph_select_spmv(G._h, 7) != 0 and b"variant" in L.gt_last_error()
     VR.free(); V.free(); G.free()
+
+
+def test_multirank_tile_rows_are_balanced(gt):
+    """Contiguous id ranges of R-MAT are badly skewed (tile-row 0 of 8 would hold ~44 % of the entries); the hashed
+    internal id space must give every rank a similar share of entries, rows and columns."""
+    from graphtap_amd.rmat import rmat_edges
+    scale, p = 18, 8
+    e = rmat_edges(scale, 16, 1)
+    nnz, rows, cols = [], [], []
+    for r in range(p):
+        G = gt.Graph(); G.load_edges(e, 1 << scale, 1 << scale, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=r, nranks=p)
+        nnz.append(G.info.nnz_local); rows.append(G.info.nnzrows); cols.append(G.info.nnzcols)
+        vids = G.vertex_ids()
+        if r == 0:
+            allv = []
+        allv.append(vids[vids != 0xFFFFFFFF])
+        G.free()
+    assert sum(nnz) == len(e)
+    assert max(nnz) < 1.25 * (sum(nnz) / p), nnz
+    assert max(rows) < 1.1 * (sum(rows) / p) and max(cols) < 1.1 * (sum(cols) / p)
+    allv = np.concatenate(allv)
+    assert allv.size == (1 << scale) + 1 and np.unique(allv).size == allv.size   # every vertex owned exactly once

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-rank compute time of the N-GPU PageRank step, measured on ONE GPU: builds tile-row `rank` of `nranks`
+of the R-MAT graph and runs the three local phases (scatter_gather, combine, apply) without the exchange.
+The missing term of a real N-GPU step is the all-gather of x (RCCL), which a 1-GPU box cannot run.
+  python tools/bench_tilerow.py --scale 26 --nranks 8 --rank 0"""
+import argparse, ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GRAPHTAP_SPMV", "pb_f32msg")
+import graphtap_amd as gt
+from graphtap_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=int, default=26); ap.add_argument("--nranks", type=int, default=8)
+ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=20)
+a = ap.parse_args()
+L = _lib.lib(); _lib.require_gpu(); _lib.check(L.gt_set_device(0))
+nv, m = 1 << a.scale, 16 << a.scale
+d = C.c_void_p(); _lib.check(L.gt_malloc(C.byref(d), m * 8)); _lib.check(L.gt_rmat_generate(d, a.scale, 1, 0, 0, m, None))
+G = gt.Graph(); G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=a.rank, nranks=a.nranks)
+_lib.check(L.gt_free(d))
+V = gt.Deg_Program(G, True, False, False, gt._COL_); V.initialize()
+h = V._handle(); _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 1, None))
+VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V)   # partial degrees: timing only
+h = VR._handle()
+_lib.check(L.gt_program_enable_timing(h, 1))
+def step():
+    _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 0x7fffffff, None))
+for _ in range(3): step()
+ms, n = C.c_double(), C.c_uint32(); _lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
+_lib.check(L.gt_device_synchronize()); t0 = time.perf_counter()
+for _ in range(a.steps): step()
+_lib.check(L.gt_device_synchronize()); dt = time.perf_counter() - t0
+_lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
+i = G.info
+print(json.dumps({"scale": a.scale, "rank": a.rank, "nranks": a.nranks, "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
+                  "seg_stride": int(i.seg_stride), "ms_per_step_compute_only": dt * 1e3 / a.steps, "spmv_ms": ms.value / max(n.value, 1),
+                  "x_exchange_bytes_f32": int(i.nranks * i.seg_stride * 4)}))
