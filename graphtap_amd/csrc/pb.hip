@@ -119,6 +119,13 @@ __global__ void k_run_keys(const uint64_t *__restrict__ key64, uint64_t n, uint3
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
         key[v] = (uint32_t)(key64[v] >> RB);
 }
+__global__ void k_count_run_rows(const uint64_t *__restrict__ key64, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        c += (i == 0 || key64[i] != key64[i - 1]);   // key = (chunk, bin, row): equal keys = same run and row
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 __global__ void k_iota(uint32_t *__restrict__ p, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
@@ -605,6 +612,12 @@ int gt_pb_build(gt_graph *g) {
     uint32_t nout = 0;
     PB_HIP(hipMemcpy(&nout, kscan.as<uint32_t>() + nrun, 4, hipMemcpyDeviceToHost));
     pb->nout = nout;
+    if (getenv("GRAPHTAP_PB_STATS")) {   // how many (run, row) groups there are at all: the limit of any in-run aggregation
+        DevBuf cntb; PB_ALLOC(cntb, 8); PB_HIP(hipMemsetAsync(cntb.p, 0, 8, s));
+        k_count_run_rows<<<grid_for(nnz), TPB, 0, s>>>(skey64, nnz, cntb.as<unsigned long long>());
+        unsigned long long uq = 0; PB_HIP(hipMemcpy(&uq, cntb.p, 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pb] distinct (run,row) groups: %llu of %u entries (factor %.3f)\n", uq, nnz, (double)nnz / uq);
+    }
     if (getenv("GRAPHTAP_PB_STATS"))
         fprintf(stderr, "[pb] value-stream slots after pre-aggregation: %u for %u entries (factor %.3f)\n", nout, nnz, (double)nnz / nout);
     k_scatter_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), kscan.as<uint32_t>(), nrun, pkstart.as<uint32_t>());
