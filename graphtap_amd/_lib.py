@@ -28,7 +28,8 @@ class GraphInfo(C.Structure):
                 ("rank", C.c_uint32), ("nranks", C.c_uint32), ("nnzrows", C.c_uint32), ("nnzcols", C.c_uint32),
                 ("seg_stride", C.c_uint32), ("nnz_local", C.c_uint64), ("nnz_global", C.c_uint64),
                 ("nnzrows_global", C.c_uint64), ("nnzcols_global", C.c_uint64), ("weighted", C.c_int32),
-                ("regular", C.c_uint32), ("source_rows", C.c_uint32), ("sink_cols", C.c_uint32)]
+                ("regular", C.c_uint32), ("source_rows", C.c_uint32), ("sink_cols", C.c_uint32),
+                ("x_slices", C.c_uint32), ("slice_width", C.c_uint32)]
 
 
 class TileArrays(C.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "gt_program_set_x": (C.c_int, [_vp, _vp]),
     "gt_program_scatter_gather": (C.c_int, [_vp]),
     "gt_program_combine": (C.c_int, [_vp]),
+    "gt_program_combine_slice": (C.c_int, [_vp, C.c_uint32]),
     "gt_program_apply": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gt_program_finish_converged": (C.c_int, [_vp]),
     "gt_program_iteration": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),

@@ -63,6 +63,7 @@ struct gt_program {
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
     bool timing = false;
+    uint32_t spmv_done = 0;     // complete SpMVs among the timed event pairs (a sliced SpMV records one pair per slice)
     uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
     bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
 };
@@ -70,23 +71,23 @@ struct gt_program {
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
 // scatter_gather_stationary vp:688-708 / _nonstationary vp:711-758 over the owned segment's
 // non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs.
-__global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[j] = 1u;  // deg.h:35-37
+__global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc, gt_xmap xm) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[gt_xpos(xm, j)] = 1u;  // deg.h:35-37
 }
 template <class TX>
 __global__ void k_msg_pr(TX *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
-                         const uint32_t *__restrict__ deg, const double *__restrict__ rank) {
+                         const uint32_t *__restrict__ deg, const double *__restrict__ rank, gt_xmap xm) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j], d = deg[v];
-        x[j] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
+        x[gt_xpos(xm, j)] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
     }
 }
 __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
-                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
+                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind, gt_xmap xm) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
         // bfs.h:52-54 (vid), sssp.h:44-46 (distance), cc.h:38-40 (label); inactive -> infinity() vp:749-750
-        x[j] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
+        x[gt_xpos(xm, j)] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
     }
 }
 
@@ -124,11 +125,11 @@ __global__ void k_apply_deg_row(const uint32_t *__restrict__ y, const uint32_t *
         deg[v] = y[r]; C[v] = 0;  // deg.h:47-50
     }
 }
-__global__ void k_apply_deg_col(const uint32_t *__restrict__ y_seg, const uint32_t *__restrict__ JC, uint32_t nc,
-                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C) {
+__global__ void k_apply_deg_col(const uint32_t *__restrict__ y, const uint32_t *__restrict__ JC, uint32_t nc,
+                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C, gt_xmap xm) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
-        deg[v] = y_seg[j]; C[v] = 0;
+        deg[v] = y[gt_xpos(xm, j)]; C[v] = 0;
     }
 }
 // PageRank in compressed-row space: applicator (pr.h:43-47) of iteration t fused with the messenger
@@ -138,7 +139,7 @@ __global__ void k_apply_deg_col(const uint32_t *__restrict__ y_seg, const uint32
 template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
-                               TX *__restrict__ x_own, double alpha, double tol, int cf, int last,
+                               TX *__restrict__ x, gt_xmap xm, double alpha, double tol, int cf, int last,
                                unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
@@ -153,7 +154,7 @@ __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restric
         const uint8_t ch = fabs(nv - tmp) > tol;
         C_c[r] = ch;
         act += (ch && !(cf && source));
-        if (!source) { const uint32_t d = deg_c[r]; x_own[c] = (TX)(d ? nv / (double)d : 0.0); }
+        if (!source) { const uint32_t d = deg_c[r]; x[gt_xpos(xm, c)] = (TX)(d ? nv / (double)d : 0.0); }
     }
     count_active(act, d_active);
 }
@@ -529,36 +530,41 @@ int gt_program_scatter_gather(gt_program *p) {
     const uint32_t nc = g->info.nnzcols;
     if (p->prm.order == GT_COL || nc == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
     if (p->x_fresh) { p->x_fresh = false; return GT_OK; }  // the fused PageRank apply already wrote them
-    const uint64_t off = (uint64_t)g->info.rank * g->info.seg_stride;
+    const gt_xmap xm = gt_xmap_of(g->info, g->info.rank);   // where the owned segment's columns sit in [K][nranks][T]
     hipStream_t s = p->stream;
     switch (p->prm.kind) {
-        case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, nc); break;
+        case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x, nc, xm); break;
         case GT_PR: {
             int st = pr_sync_state(p); if (st != GT_OK) return st;
-            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)p->x + off, g->JC, nc, p->s0, p->rank);
-            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)p->x + off, g->JC, nc, p->s0, p->rank);
+            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)p->x, g->JC, nc, p->s0, p->rank, xm);
+            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)p->x, g->JC, nc, p->s0, p->rank, xm);
             break;
         }
         default:
-            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x + off, g->JC, nc, p->C, p->s0,
-                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
+            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x, g->JC, nc, p->C, p->s0,
+                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind, xm);
             break;
     }
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
-static int combine_impl(gt_program *p, bool timed) {
+// slices [lo, hi) of the K = x_slices steps of one SpMV; the accumulators are complete after hi == K
+static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
     const gt_graph *g = p->g;
     hipStream_t s = p->stream;
+    const uint32_t K = g->info.x_slices;
     if (p->converged) return GT_OK;  // vp:1025, 1044: nothing visible happens once converged
     if (p->prm.order == GT_COL) {
+        if (hi < K) return GT_OK;
         k_col_counts<<<grid_for(g->ncols_total), TPB, 0, s>>>(g->JA, g->ncols_total, (uint32_t *)p->y);
         GT_HIP(hipGetLastError());
         return GT_OK;
     }
-    if (p->stationary && !p->y_clean) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
-    p->y_clean = false;
+    if (lo == 0) {
+        if (p->stationary && !p->y_clean) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
+        p->y_clean = false;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         if (p->ev_used + 2 > p->ev.size()) {
@@ -569,14 +575,19 @@ static int combine_impl(gt_program *p, bool timed) {
         e0 = p->ev[p->ev_used]; e1 = p->ev[p->ev_used + 1]; p->ev_used += 2;
         GT_HIP(hipEventRecord(e0, s));
     }
-    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch);
+    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi);
     if (st != GT_OK) return st;
-    if (timed) GT_HIP(hipEventRecord(e1, s));
+    if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
     return GT_OK;
 }
 int gt_program_combine(gt_program *p) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "combine before initialize");
-    return combine_impl(p, p->timing);
+    return combine_impl(p, p->timing, 0, p->g->info.x_slices);
+}
+int gt_program_combine_slice(gt_program *p, uint32_t k) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "combine before initialize");
+    GT_REQUIRE(k < p->g->info.x_slices, GT_ERR_INVALID, "slice %u of %u", k, p->g->info.x_slices);
+    return combine_impl(p, p->timing, k, k + 1);
 }
 int gt_program_enable_timing(gt_program *p, int on) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
@@ -590,9 +601,10 @@ int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int re
     for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
         float ms = 0;
         GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
-        *spmv_ms += ms; (*launches)++;
+        *spmv_ms += ms;
     }
-    if (reset) p->ev_used = 0;
+    *launches = p->spmv_done;   // complete SpMVs (a sliced SpMV contributes one event pair per slice to the sum)
+    if (reset) { p->ev_used = 0; p->spmv_done = 0; }
     return GT_OK;
 }
 
@@ -610,19 +622,19 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         case GT_DEG:
             if (p->prm.order == GT_COL) {
                 if (g->info.nnzcols)
-                    k_apply_deg_col<<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)p->y + (uint64_t)g->info.rank * g->info.seg_stride,
-                                                                              g->JC, g->info.nnzcols, p->s0, p->C);
+                    k_apply_deg_col<<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)p->y, g->JC, g->info.nnzcols, p->s0, p->C,
+                                                                              gt_xmap_of(g->info, g->info.rank));
             } else if (nr) k_apply_deg_row<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C);
             break;
         case GT_PR: {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
-            // x may be a caller-installed buffer (multi-rank): the owned segment starts at rank * seg_stride
-            const uint64_t xoff = (uint64_t)g->info.rank * g->info.seg_stride;
+            // x may be a caller-installed buffer (multi-rank); the owned segment's columns sit at gt_xpos(xm, .)
+            const gt_xmap xm = gt_xmap_of(g->info, g->info.rank);
             if (nr && p->x_f32)
-                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)p->x + xoff,
+                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)p->x, xm,
                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active);
             else if (nr)
-                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)p->x + xoff,
+                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)p->x, xm,
                                                                     p->prm.alpha, p->prm.tol, cf, last, d_active);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
@@ -663,12 +675,12 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     if (!p->initialized) { int st = init_common(p); if (st != GT_OK) return st; }  // vp:410-411
     const bool check = (iters == 0);                                               // vp:412-413
     hipStream_t s = p->stream;
-    p->ev_used = 0;
+    p->ev_used = 0; p->spmv_done = 0;
     GT_HIP(hipStreamSynchronize(s));
     auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
-        st = combine_impl(p, stats != nullptr); if (st != GT_OK) return st;
+        st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
         uint64_t active = 0;
         st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
         if (check) {

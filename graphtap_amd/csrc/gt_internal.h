@@ -49,11 +49,19 @@ struct gt_graph {
     int spmv_variant = 1;        // gt_spmv_variant
 };
 
+#define GT_PB_WINDOW 8192u   // columns per phase-1 window (pb.hip); slice widths are multiples of it
+
+// position of compressed column j of segment s in the message vector [K][nranks][T]
+struct gt_xmap { uint32_t T, pT, sT; };   // slice width, nranks * T, s * T
+__host__ __device__ inline uint32_t gt_xpos(const gt_xmap &m, uint32_t j) { const uint32_t k = j / m.T; return k * m.pT + m.sT + (j - k * m.T); }
+inline gt_xmap gt_xmap_of(const gt_graph_info &i, uint32_t seg) { return gt_xmap{i.slice_width, i.nranks * i.slice_width, seg * i.slice_width}; }
+
 // pb.hip
 int gt_pb_build(gt_graph *g);
 void gt_pb_free(struct gt_pb *pb);
+// slices [slice_lo, slice_hi) of phase 1; phase 2 runs when slice_hi == x_slices
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch);
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
@@ -74,4 +82,4 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
-                   const void *owner = nullptr, uint64_t epoch = 0);
+                   const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu);

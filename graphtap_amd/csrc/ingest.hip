@@ -9,6 +9,7 @@
 // Every rank sees the full edge list (replicated ingest) and keeps tile-row `rank`.
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <vector>
 
 #include "gt_internal.h"
@@ -76,6 +77,18 @@ struct U8ToU32 {
     __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; }
 };
 
+// ---- column ids of the message vector: (segment, compressed column) -> slot in [K][nranks][T]. Done BEFORE the sort
+// so that the entries come out ordered by the id the kernels use (with K > 1 it is not monotone in the vertex id).
+__global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ Scol, uint32_t H, uint32_t T, uint32_t pT) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        if (k == KEY_INVALID) continue;
+        const uint32_t col = (uint32_t)(k >> 32), seg = col / H;
+        const uint32_t c = gt_xpos(gt_xmap{T, pT, seg * T}, Scol[col] - Scol[seg * H]);
+        keys[i] = ((uint64_t)c << 32) | (uint32_t)k;
+    }
+}
+
 // ---- dedupe: head flags over the sorted keys (matrix.hpp:545, 553: same row and col) ----
 __global__ void k_head_flags(const uint64_t *__restrict__ keys, uint64_t n, int dedupe, uint32_t *__restrict__ head) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
@@ -85,16 +98,14 @@ __global__ void k_head_flags(const uint64_t *__restrict__ keys, uint64_t n, int 
 // ---- populate: compressed ids of every kept entry (compressed_column.hpp:382-394) -------
 __global__ void k_populate(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ wts, uint64_t n,
                            const uint32_t *__restrict__ head, const uint32_t *__restrict__ pos,
-                           const uint32_t *__restrict__ Srow, const uint32_t *__restrict__ Scol,
-                           uint32_t H, uint32_t row_lo, uint32_t seg_stride,
+                           const uint32_t *__restrict__ Srow, uint32_t row_lo,
                            uint32_t *__restrict__ IA, uint32_t *__restrict__ JI, uint32_t *__restrict__ A) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (!head[i]) continue;
         uint32_t o = pos[i];
-        uint32_t row = (uint32_t)keys[i], col = (uint32_t)(keys[i] >> 32);
-        uint32_t seg = col / H;
+        const uint32_t row = (uint32_t)keys[i];
         IA[o] = Srow[row] - Srow[row_lo];
-        JI[o] = seg * seg_stride + (Scol[col] - Scol[seg * H]);
+        JI[o] = (uint32_t)(keys[i] >> 32);   // already the message-vector slot (k_remap_cols)
         if (A) A[o] = wts[i];
     }
 }
@@ -208,6 +219,19 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     uint32_t seg_stride = 0;
     for (uint32_t q = 0; q < p; q++) seg_stride = std::max(seg_stride, segc[q + 1] - segc[q]);
     if (seg_stride == 0) seg_stride = 1;
+    // Several ranks: the message vector is cut into K slices [K][nranks][T] so that the exchange of slice k+1 can overlap
+    // phase 1 of slice k; T is a multiple of the phase-1 window so that no window straddles two slices.
+    uint32_t K = 1;
+    if (p > 1) {
+        const char *e = getenv("GRAPHTAP_X_SLICES");
+        K = e ? (uint32_t)atoi(e) : 4u;
+        if (K < 1) K = 1;
+        if (K > 64) K = 64;
+    }
+    uint32_t T = (seg_stride + K - 1) / K;
+    if (K > 1) T = (T + GT_PB_WINDOW - 1) / GT_PB_WINDOW * GT_PB_WINDOW;
+    seg_stride = K * T;
+    g->info.x_slices = K; g->info.slice_width = T;
     g->info.nnzrows = segr[k + 1] - segr[k];
     g->info.nnzcols = segc[k + 1] - segc[k];
     g->info.seg_stride = seg_stride;
@@ -216,6 +240,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     GT_REQUIRE((uint64_t)p * seg_stride < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "column id space exceeds 32 bits");
     g->ncols_total = p * seg_stride;
 
+    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), H, g->info.slice_width, p * g->info.slice_width);
     // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
     // so that the first copy of a duplicate (row,col) carries its minimum weight. Invalid keys sink
     // to the end. Radix sort is stable.
@@ -277,7 +302,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     }
     if (nvalid)
         k_populate<<<grid_for(nvalid), TPB, 0, s>>>(sorted_keys, sorted_wts, nvalid, head.as<uint32_t>(), pos.as<uint32_t>(),
-                                                    Srow.as<uint32_t>(), Scol.as<uint32_t>(), H, row_lo, seg_stride,
+                                                    Srow.as<uint32_t>(), row_lo,
                                                     g->IA, g->JI, g->A);
     k_col_ptr<<<grid_for((uint64_t)g->ncols_total + 1), TPB, 0, s>>>(g->JI, nnz, g->ncols_total, g->JA);
     unsigned int *classes = (unsigned int *)(counters.as<unsigned long long>() + 4);

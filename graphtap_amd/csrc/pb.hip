@@ -47,7 +47,7 @@ namespace {
 
 constexpr int RB = 14;                 // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS
-constexpr uint32_t W = 8192;           // columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
+constexpr uint32_t W = GT_PB_WINDOW;   // 8192 columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
 // Entries per chunk: large chunks make long runs (mean run ~300 entries at 2^20 on R-MAT-26), but the grid
 // must still be several times the 512 resident phase-1 workgroups: aim at >= ~1024 entry-limited chunks.
 static uint32_t ch_default(uint32_t nnz) {
@@ -285,10 +285,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nquads,
                                                            const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
-                                                           const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active) {
+                                                           const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
+                                                           uint32_t chunk0) {
     __shared__ TV xwin[W + 64];
     __shared__ TV stage[P1_THREADS / 64][256];   // per-wave compaction row for the outputs of one 256-entry group
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = chunk0 + blockIdx.x;
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
@@ -466,6 +467,7 @@ struct gt_pb {
     uint32_t *WT = nullptr, *KSTART = nullptr;
     void *G = nullptr;         // GroupRec per 256 padded entries
     BinWork *work = nullptr;
+    std::vector<uint32_t> slice_chunk;   // chunks of slice k of the message vector: [slice_chunk[k], slice_chunk[k+1])
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
@@ -659,6 +661,16 @@ int gt_pb_build(gt_graph *g) {
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
     if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
     PB_MALLOC(pb->chunk_active, (uint64_t)nchunks * 4); PB_MALLOC(pb->active_prefix, (uint64_t)(nchunks + 1) * 4);
+    {   // chunks are in column order and no window straddles a slice (slice_width is a multiple of W when K > 1)
+        const uint32_t K = g->info.x_slices;
+        const uint64_t pT = (uint64_t)g->info.nranks * g->info.slice_width;
+        std::vector<uint32_t> hcol(nchunks);
+        PB_HIP(hipMemcpy(hcol.data(), pb->ccol0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        pb->slice_chunk.assign(K + 1, nchunks);
+        pb->slice_chunk[0] = 0;
+        for (uint32_t k = 1; k < K; k++)
+            pb->slice_chunk[k] = (uint32_t)(std::lower_bound(hcol.begin(), hcol.end(), (uint32_t)(k * pT)) - hcol.begin());
+    }
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
     g->pb = pb;
@@ -666,27 +678,35 @@ int gt_pb_build(gt_graph *g) {
 }
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
-static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch) {
+static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
+                  uint32_t slice_lo, uint32_t slice_hi) {
+    const uint32_t K = g->info.x_slices;
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see k_pb_scatter).
-    bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
-    if (filter && (pb->val_owner != owner || pb->val_epoch != epoch)) { pb->val_min = -1; pb->val_owner = owner; pb->val_epoch = epoch; }
-    if (!filter) pb->val_owner = nullptr;
-    if (pb->val_min != (IS_MIN ? 1 : 0)) {   // pad slots (and, with filtering, every slot) start at the semiring's neutral value
-        k_fill_t<TV><<<grid_for(pb->nout), TPB, 0, s>>>((TV *)pb->VAL, pb->nout, IS_MIN ? (TV)GT_INF : (TV)0);
-        pb->val_min = IS_MIN ? 1 : 0;
+    const bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
+    if (slice_lo == 0) {
+        if (filter && (pb->val_owner != owner || pb->val_epoch != epoch)) { pb->val_min = -1; pb->val_owner = owner; pb->val_epoch = epoch; }
+        if (!filter) pb->val_owner = nullptr;
+        if (pb->val_min != (IS_MIN ? 1 : 0)) {   // pad slots (and, with filtering, every slot) start at the semiring's neutral value
+            k_fill_t<TV><<<grid_for(pb->nout), TPB, 0, s>>>((TV *)pb->VAL, pb->nout, IS_MIN ? (TV)GT_INF : (TV)0);
+            pb->val_min = IS_MIN ? 1 : 0;
+        }
     }
-    k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<pb->nchunks, P1_THREADS, 0, s>>>(
-        pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
-        (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr);
-    if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
-    k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
-                                                                filter ? pb->active_prefix : nullptr);
+    const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
+    if (c1 > c0)
+        k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
+            pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
+            (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, c0);
+    if (slice_hi >= K) {
+        if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
+        k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
+                                                                    filter ? pb->active_prefix : nullptr);
+    }
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch) {
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -704,14 +724,14 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

@@ -6,7 +6,7 @@ p=2): rank k owns vertex segment k (height H = nrows/p + 1, src/mat/matrix.hpp:1
 of the p x p grid. Every iteration
 
   scatter_gather  rank k computes the messages x_k of ITS non-empty columns   (vp:688-758)
-  exchange        all-gather of the p segments of x                          (replaces the
+  exchange        all-gather of the p segments of x, in K slices                (replaces the
                   MPI_Ibcast down column groups, vp:843-862 / 970-1013)
   combine         local SpMV over tile-row k; y_k is complete, no row-group reduce is needed
                   (the reference's M6/M7 Isend/Irecv, vp:1083-1111, disappears with a = 1)
@@ -45,17 +45,32 @@ def all_reduce_sum(t, group=None):
 
 
 def run(engine, iters, group=None):
-    """Vertex_Program::execute (vp:408-441) across ranks. Returns (iterations, converged)."""
+    """Vertex_Program::execute (vp:408-441) across ranks. Returns (iterations, converged).
+
+    The message vector is [K][p][T] (K = engine.x_slices slices of width T of every rank's segment). With K > 1
+    the K all-gathers of an iteration are issued back to back (async_op) on RCCL's stream and the local SpMV is
+    driven slice by slice: phase 1 of slice k runs while slices k+1.. are still in flight."""
     check = (iters == 0)
-    p, k, stride = engine.nranks, engine.rank, engine.seg_stride
-    x = engine.x_tensor()               # [p * stride] messages, segment s at [s*stride, (s+1)*stride)
-    mine = x[k * stride:(k + 1) * stride]
+    p, k = engine.nranks, engine.rank
+    K = getattr(engine, "x_slices", 1)
+    x = engine.x_tensor()               # [K * p * T] messages
+    T = x.numel() // (K * p)
+    slices = [x[s * p * T:(s + 1) * p * T] for s in range(K)]
+    mine = [sl[k * T:(k + 1) * T] for sl in slices]
+    pipelined = p > 1 and K > 1 and engine.needs_x_exchange and not _staged(x) and hasattr(engine, "combine_slice")
     converged = False
     while True:
         engine.scatter_gather()
-        if p > 1 and engine.needs_x_exchange:
-            all_gather_segments(x, mine, group=group)
-        engine.combine()
+        if pipelined:
+            works = [dist.all_gather_into_tensor(slices[s], mine[s], group=group, async_op=True) for s in range(K)]
+            for s in range(K):
+                works[s].wait()          # the compute stream waits for slice s only
+                engine.combine_slice(s)
+        else:
+            if p > 1 and engine.needs_x_exchange:
+                for s in range(K):
+                    all_gather_segments(slices[s], mine[s], group=group)
+            engine.combine()
         if p > 1 and engine.column_accumulators:
             all_reduce_sum(engine.y_tensor(), group=group)
         active = engine.apply(iters, check)

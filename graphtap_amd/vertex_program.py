@@ -38,6 +38,7 @@ class _HipEngine:
         self.prog = prog
         i = prog.G.info
         self.rank, self.nranks, self.seg_stride = i.rank, i.nranks, i.seg_stride
+        self.x_slices, self.slice_width = i.x_slices, i.slice_width
         self.column_accumulators = (prog.ordering_type == _COL_)
         self.needs_x_exchange = not self.column_accumulators
         self._x = self._y = None
@@ -84,6 +85,9 @@ class _HipEngine:
 
     def combine(self):
         check(lib().gt_program_combine(self.prog._h))
+
+    def combine_slice(self, k):
+        check(lib().gt_program_combine_slice(self.prog._h, k))
 
     def apply(self, iters, want_active):
         a = C.c_uint64(0)

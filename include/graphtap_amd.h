@@ -79,12 +79,15 @@ typedef struct gt_graph_info {
     uint32_t rank, nranks;  /* this handle holds tile-row `rank` of the p x p grid */
     uint32_t nnzrows;       /* non-empty rows of the owned segment                */
     uint32_t nnzcols;       /* non-empty columns of the owned segment             */
-    uint32_t seg_stride;    /* max over segments of nnzcols: x is [nranks][seg_stride] */
+    uint32_t seg_stride;    /* message slots per segment (>= every segment's nnzcols): x has nranks*seg_stride elements */
     uint64_t nnz_local;     /* stored entries in this tile-row                    */
     uint64_t nnz_global;    /* stored entries over all tile-rows (TEPS denominator) */
     uint64_t nnzrows_global, nnzcols_global;
     int32_t weighted;
     uint32_t regular, source_rows, sink_cols; /* owned-segment class counts (matrix.hpp:1125-1144) */
+    uint32_t x_slices;      /* K: the message vector is [K][nranks][slice_width] (K = 1 on one rank)      */
+    uint32_t slice_width;   /* T = seg_stride / K; compressed column j of segment s sits at
+                               (j / T) * nranks * T + s * T + j % T                                      */
 } gt_graph_info;
 
 /* Device pointers to the owned tile-row in TCSC form (ds/compressed_column.hpp:287-296).
@@ -182,9 +185,9 @@ int gt_program_enable_timing(gt_program *p, int on);
 int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int reset);
 
 /* phase level, for the multi-GPU driver (graphtap_amd/dist.py) ------------
- * x is one device buffer of nranks*seg_stride messages (f64 for PageRank -- f32
+ * x is one device buffer of nranks*seg_stride messages laid out [x_slices][nranks][slice_width] (f64 for PageRank -- f32
  * when the graph's SpMV variant is GT_SPMV_PB_F32MSG at program creation -- u32
- * otherwise; gt_program_x reports the element width), segment s at [s*seg_stride, (s+1)*seg_stride). The engine owns a
+ * otherwise; gt_program_x reports the element width); with one slice segment s is [s*seg_stride, (s+1)*seg_stride). The engine owns a
  * default buffer; a caller that exchanges through its own allocation (a torch
  * tensor handed to RCCL) installs it with gt_program_set_x. */
 int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
@@ -193,6 +196,10 @@ int gt_program_set_x(gt_program *p, void *dev_ptr);
 int gt_program_scatter_gather(gt_program *p);
 /* combine(), vp:1017-1113 for the local tile-row (all column segments of x must be current) */
 int gt_program_combine(gt_program *p);
+/* The same in K = x_slices steps, so that the exchange of slice k+1 can overlap the work on slice k: step k
+ * needs only slice k of x (all segments); the accumulators are complete after step K-1. Steps must be issued in
+ * order 0..K-1. */
+int gt_program_combine_slice(gt_program *p, uint32_t k);
 /* apply(), vp:1610-1802, then iteration++. active (nullable) receives the number of
  * owned vertices whose applicator returned true -- the local term of has_converged(),
  * vp:1885-1923 (regular rows only under GT_TCSC_CF); reading it waits for the stream. */

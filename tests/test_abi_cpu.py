@@ -31,7 +31,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from graphtap_amd import _lib
     assert C.sizeof(_lib.GraphFlags) == 20
-    assert C.sizeof(_lib.GraphInfo) == 4 * 8 + 8 * 4 + 4 * 4
+    assert C.sizeof(_lib.GraphInfo) == 4 * 8 + 8 * 4 + 4 * 4 + 8
     assert C.sizeof(_lib.ProgramParams) == 32
     assert C.sizeof(_lib.ExecStats) == 32
 

@@ -23,7 +23,7 @@ INF = 2147483647
 class NumpyTileEngine:
     """One rank's tile-row, same five phase methods as vertex_program._HipEngine."""
 
-    def __init__(self, kind, rank, nranks, edges, nv, root=0, order_col=False):
+    def __init__(self, kind, rank, nranks, edges, nv, root=0, order_col=False, x_slices=2):
         from oracle import oracle as O
         self.kind, self.rank, self.nranks, self.root = kind, rank, nranks, root
         app = {"deg": "pr", "pr": "pr", "bfs": "bfs", "sssp": "sssp", "cc": "cc"}[kind]
@@ -40,12 +40,16 @@ class NumpyTileEngine:
         rowflag[rows_v] = True; colflag[cols_v] = True
         Srow = np.concatenate([[0], np.cumsum(rowflag)]); Scol = np.concatenate([[0], np.cumsum(colflag)])
         nnzcols_seg = [Scol[(s + 1) * H] - Scol[s * H] for s in range(p)]
-        self.seg_stride = stride = max(max(nnzcols_seg), 1)
+        # message vector [K][p][T]: slot of compressed column j of segment s = (j // T) * p * T + s * T + j % T
+        self.x_slices = K = x_slices
+        self.T = T = -(-max(max(nnzcols_seg), 1) // K)
+        self.seg_stride = stride = K * T
         lo = rank * H
         mine = (rows_v // H) == rank
         self.r = (Srow[rows_v[mine]] - Srow[lo]).astype(np.int64)            # local compressed row
         cseg = cols_v[mine] // H
-        self.c = (cseg * stride + Scol[cols_v[mine]] - Scol[cseg * H]).astype(np.int64)
+        j = Scol[cols_v[mine]] - Scol[cseg * H]
+        self.c = ((j // T) * p * T + cseg * T + j % T).astype(np.int64)
         self.w = w[mine] if w is not None else None
         self.nnz_local = int(mine.sum())
         self.I = rowflag[lo:lo + H]; self.J = colflag[lo:lo + H]
@@ -75,9 +79,13 @@ class NumpyTileEngine:
     def x_tensor(self): return torch.from_numpy(self.x)
     def y_tensor(self): return torch.from_numpy(self.y)
 
+    def _own(self):
+        j = np.arange(self.nc)
+        return (j // self.T) * self.nranks * self.T + self.rank * self.T + j % self.T
+
     def scatter_gather(self):
         if self.column_accumulators: return
-        s = slice(self.rank * self.seg_stride, self.rank * self.seg_stride + self.nc)
+        s = self._own()
         v = self.JC
         if self.kind == "deg": self.x[s] = 1
         elif self.kind == "pr": self.x[s] = np.where(self.degree[v] > 0, self.rank_[v] / np.maximum(self.degree[v], 1), 0.0)
@@ -85,18 +93,25 @@ class NumpyTileEngine:
         else: self.x[s] = np.where(self.C[v], self.s0[v], INF)
 
     def combine(self):
+        for k in range(self.x_slices): self.combine_slice(k)
+
+    def combine_slice(self, k):
+        """entries whose column lies in slice k of the message vector (only that slice of x is guaranteed current)"""
         if self.converged: return
         if self.column_accumulators:
-            self.y[:] = np.bincount(self.c, minlength=self.y.size); return
+            if k == self.x_slices - 1: self.y[:] = np.bincount(self.c, minlength=self.y.size)
+            return
+        pT = self.nranks * self.T
+        sel = (self.c // pT) == k
         if self.kind in ("deg", "pr"):
-            self.y[:] = 0
-            np.add.at(self.y, self.r, self.x[self.c])
+            if k == 0: self.y[:] = 0
+            np.add.at(self.y, self.r[sel], self.x[self.c[sel]])
         else:
-            xv = self.x[self.c].astype(np.int64)
+            xv = self.x[self.c[sel]].astype(np.int64)
             ok = xv != INF
-            cand = xv + (self.w if self.w is not None else 0)
+            cand = xv + (self.w[sel] if self.w is not None else 0)
             y = self.y.astype(np.int64)
-            np.minimum.at(y, self.r[ok], cand[ok])
+            np.minimum.at(y, self.r[sel][ok], cand[ok])
             self.y[:] = y
 
     def apply(self, iters, want_active):
@@ -105,7 +120,7 @@ class NumpyTileEngine:
         if self.iteration == 0: self.C[~self.I] = False
         if self.kind == "deg":
             if self.column_accumulators:
-                self.degree[self.JC] = self.y[self.rank * self.seg_stride: self.rank * self.seg_stride + self.nc]; self.C[self.JC] = False
+                self.degree[self.JC] = self.y[self._own()]; self.C[self.JC] = False
             else:
                 self.degree[v] = self.y; self.C[v] = False
         elif self.kind == "pr":

@@ -293,12 +293,20 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
         stride = engs[0].seg_stride
         while True:
             for e_ in engs: e_.scatter_gather()
-            if engs[0].needs_x_exchange:
+            if engs[0].needs_x_exchange:   # the all-gather of every slice [K][p][T], by device copies
                 xs = [e_.x_tensor() for e_ in engs]
-                for r, xr in enumerate(xs):
-                    for q, xq in enumerate(xs):
-                        if q != r: xq[r * stride:(r + 1) * stride].copy_(xr[r * stride:(r + 1) * stride])
-            for e_ in engs: e_.combine()
+                K, T = engs[0].x_slices, engs[0].slice_width
+                assert K * T == stride and xs[0].numel() == nranks * stride
+                for k in range(K):
+                    for r, xr in enumerate(xs):
+                        a = k * nranks * T + r * T
+                        for q, xq in enumerate(xs):
+                            if q != r: xq[a:a + T].copy_(xr[a:a + T])
+            if engs[0].x_slices > 1 and (len(progs) + engs[0].iteration) % 2 == 0:   # exercise the sliced entry point too
+                for k in range(engs[0].x_slices):
+                    for e_ in engs: e_.combine_slice(k)
+            else:
+                for e_ in engs: e_.combine()
             if engs[0].column_accumulators:
                 tot = sum(e_.y_tensor().clone() for e_ in engs)
                 for e_ in engs: e_.y_tensor().copy_(tot)
