@@ -11,6 +11,7 @@ int main(int argc, char **argv) try {
     gt::Deg_Program V(G, true, false, false, gt::_ROW_);
     V.execute(1);
     V.checksum();
+    V.checksum1(GT_F_DEGREE);   // deg.cpp:43
     V.display();
     V.free();
     G.free();

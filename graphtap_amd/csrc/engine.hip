@@ -678,11 +678,25 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     p->ev_used = 0; p->spmv_done = 0;
     GT_HIP(hipStreamSynchronize(s));
     auto t0 = std::chrono::steady_clock::now();
+    // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
+    // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
+    const bool phase_timing = stats != nullptr && getenv("GRAPHTAP_TIMING") != nullptr;
+    double t_sg = 0, t_cb = 0, t_ap = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc) -> int {
+        if (phase_timing) GT_HIP(hipStreamSynchronize(s));
+        auto t2 = now(); acc += std::chrono::duration<double, std::milli>(t2 - t).count(); t = t2;
+        return GT_OK;
+    };
     for (;;) {
+        auto tp = now();
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        st = lap(tp, t_sg); if (st != GT_OK) return st;
         st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
+        st = lap(tp, t_cb); if (st != GT_OK) return st;
         uint64_t active = 0;
         st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
+        st = lap(tp, t_ap); if (st != GT_OK) return st;
         if (check) {
             if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
         } else if (p->iteration >= iters) break;
@@ -693,6 +707,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         memset(stats, 0, sizeof(*stats));
         stats->iterations = p->iteration; stats->converged = p->converged;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

@@ -116,6 +116,10 @@ typedef struct gt_exec_stats {
     double spmv_ms;        /* sum of SpMV kernel durations (HIP events on the handle's stream) */
     uint32_t spmv_launches;
     uint32_t reserved;
+    /* the reference's -DTIMING record (vp:2134-2152), host wall time of the three phases summed over the
+     * iterations of this call; phases are enqueued asynchronously, so they only add up to `seconds` when the
+     * library is asked to drain the stream after each phase (environment GRAPHTAP_TIMING=1) */
+    double scatter_gather_ms, combine_ms, apply_ms;
 } gt_exec_stats;
 
 /* state fields for gt_program_copy_state */

@@ -17,7 +17,9 @@
 //  * V is struct-of-arrays copied out of HBM on demand (`V()`), not a std::vector of structs.
 #pragma once
 #include <chrono>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <stdexcept>
@@ -97,11 +99,29 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
         iteration = stats.iterations;
         for (uint32_t i = 1; i <= iteration; i++) printf("Iteration:  %u\n", i);  // vp:422
         printf("Execute time: %f seconds\n", stats.seconds);                       // vp:437
+        if (getenv("GRAPHTAP_TIMING"))   // the reference's -DTIMING record, vp:2145-2152 (sums only: one call, no per-iteration std-dev)
+            printf("TIMING scatter_gather %f combine %f apply %f execute %f ms (SpMV kernels %f ms over %u launches)\n",
+                   stats.scatter_gather_ms, stats.combine_ms, stats.apply_ms, stats.seconds * 1e3, stats.spmv_ms, stats.spmv_launches);
     }
     void checksum() {  // vp:1927-1960
         uint64_t s = 0, c = 0;
         check(gt_program_checksum(handle(), &s, &c));
         printf("Iterations: %u\nValue checksum: %llu\nReachable vertices: %llu\n", iteration, (unsigned long long)s, (unsigned long long)c);
+    }
+    // checksum1(), vp:1963-2119: statistics of an integer state (used by apps/deg.cpp on the degrees)
+    void checksum1(int field) {
+        const uint32_t H = G_.info.tile_height, n = G_.info.nrows;
+        std::vector<uint32_t> v = state_u32(field, H);
+        uint64_t sum = 0; double sq = 0; uint32_t maxv = 0, maxi = 0;
+        for (uint32_t i = 0; i < H && i < n; i++) { sum += v[i]; sq += (double)v[i] * v[i]; if (v[i] > maxv) { maxv = v[i]; maxi = i; } }
+        std::vector<uint32_t> hist(maxv + 1, 0);
+        for (uint32_t i = 0; i < H; i++) hist[i < n ? v[i] : 0]++;   // the reference counts padding slots as value 0
+        uint32_t mode = 0; for (uint32_t k = 1; k <= maxv; k++) if (hist[k] > hist[mode]) mode = k;
+        const double mean = (double)sum / n, sd = std::sqrt(sq / n - mean * mean);
+        printf("Value checksum: %llu\n", (unsigned long long)sum);
+        printf("Sum: mean +/- std_dev: %f: %f +/- %f\n", (double)sum, mean, sd);   // std::fixed is in effect in the reference
+        printf("Mode & skew : %u & %f\n", mode, (mean - mode) / sd);
+        printf("Max index : %u\nMax value : %u\n", maxi, maxv);
     }
     virtual std::string print_state(uint32_t i) = 0;
     void display(uint32_t count = 31) {  // vp:2124-2181

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.GraphFlags) == 20
     assert C.sizeof(_lib.GraphInfo) == 4 * 8 + 8 * 4 + 4 * 4 + 8
     assert C.sizeof(_lib.ProgramParams) == 32
-    assert C.sizeof(_lib.ExecStats) == 32
+    assert C.sizeof(_lib.ExecStats) == 56
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -65,3 +65,18 @@ def test_bfs_cc_sssp_deg_mains(known_answers):
 def test_missing_file_is_an_error_not_a_crash():
     r = run("pr", "/nonexistent/file.bin", 1024, 20)
     assert r.returncode == 1 and "Unable to open input file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_deg_checksum1_and_timing_record():
+    """checksum1 statistics (vp:1963-2119) as printed by the reference's `deg` on its bundled sample, and the
+    -DTIMING-style record."""
+    env = dict(os.environ, GRAPHTAP_TIMING="1")
+    exe = os.path.join(BIN, "deg")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "rmat10_1024.bin"), "1024"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    # lines printed by the unmodified reference (oracle/_ref/deg tests/golden/rmat10_1024.bin 1024)
+    assert "Sum: mean +/- std_dev: 16384.000000: 15.984390 +/- 81.271468" in r.stdout
+    assert "Mode & skew : 0 & 0.196679" in r.stdout
+    assert "Max index : 613" in r.stdout and "Max value : 1983" in r.stdout
+    assert "TIMING scatter_gather" in r.stdout
