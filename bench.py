@@ -90,7 +90,7 @@ def cpu_baseline_reference(e, scale, seed, iters=20, nproc=8):
         try:
             t0 = time.perf_counter()
             r = subprocess.run([mpirun, "-np", str(nproc), exe, path, str(1 << scale), str(iters)], env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=150)
             wall = time.perf_counter() - t0
         except Exception:
             return None

@@ -276,6 +276,7 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
     from graphtap_amd import dist as gdist
     from graphtap_amd.vertex_program import _HipEngine
     monkeypatch.setenv("GRAPHTAP_SPMV", variant)   # read by gt_graph_build
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str({"pb": 4, "pb_f32msg": 2, "edge": 1}[variant]))   # K of the [K][p][T] message layout
     c = load_case(name); nv = c["num_vertices"]; n = nv + 1
 
     class Loopback:
