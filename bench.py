@@ -13,7 +13,7 @@ here too; by default the per-edge messages are rounded to f32 in flight (--spmv 
 relative rank error 3.7e-8 against the fp64 oracle, tests/test_gpu_parity.py; BASELINE.json quotes
 the GPU configuration as fp32 with a 1e-6 tolerance). --spmv pb keeps the messages in f64.
 For N > 1 the SAME graph is split by tile-rows over the N GPUs (strong scaling); the only
-collective on the data path is the all-gather of the message vector x (graphtap_amd/dist.py).
+collective on the data path is the all-to-all of the needed columns of the message vector x (graphtap_amd/dist.py).
 
 Timed region: exactly K steps, bracketed by barrier + device synchronize on both sides, MAX over
 ranks. The edge list is generated in HBM and the TCSC build runs on the device before the timed
@@ -199,9 +199,9 @@ def main():
 
     i = G.info
     F = 8
-    b_alg = 4 * i.nnz_local + 4 * (i.nranks * i.seg_stride + 1) + F * i.nranks * i.seg_stride + F * i.nnzrows
-    if world == 1:
-        b_alg = 4 * i.nnz_local + 4 * (i.nnzcols + 1) + F * i.nnzcols + F * i.nnzrows
+    # IA + JA + x + y of the tile-row (on several ranks x / JA span the ncols_local columns the tile-row reads)
+    ncols = i.nnzcols if world == 1 else i.ncols_local
+    b_alg = 4 * i.nnz_local + 4 * (ncols + 1) + F * ncols + F * i.nnzrows
     kernel_ms = spmv_ms / launches
     t = torch.tensor([dt, kernel_ms, float(b_alg)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -227,7 +227,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(i.nnzrows_global), "nnzcols": int(i.nnzcols_global),
-                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), all-gather of x per step" % world if world > 1 else "single tile",
+                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if world > 1 else "single tile",
                    "ingress_s": round(t_ingress, 3), "iterations_total": VR.iteration, "value_checksum": checksum[0], "reachable": checksum[1]},
         "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter<double,double> + k_pb_gather<double,double> (one SpMV = this launch pair)",
                                                   "pb_f32msg": "k_pb_scatter<double,float> + k_pb_gather<double,float> (one SpMV = this launch pair)",

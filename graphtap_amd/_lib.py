@@ -29,11 +29,17 @@ class GraphInfo(C.Structure):
                 ("seg_stride", C.c_uint32), ("nnz_local", C.c_uint64), ("nnz_global", C.c_uint64),
                 ("nnzrows_global", C.c_uint64), ("nnzcols_global", C.c_uint64), ("weighted", C.c_int32),
                 ("regular", C.c_uint32), ("source_rows", C.c_uint32), ("sink_cols", C.c_uint32),
-                ("x_slices", C.c_uint32), ("slice_width", C.c_uint32)]
+                ("x_slices", C.c_uint32), ("slice_width", C.c_uint32), ("ncols_local", C.c_uint32), ("send_elems", C.c_uint32)]
 
 
 class TileArrays(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("JA", "IA", "A", "JC", "IR")]
+    _fields_ = [(n, C.c_void_p) for n in ("JA", "IA", "A", "JC", "IR", "L2G")]
+
+
+class ExchangePlan(C.Structure):
+    _fields_ = [("nranks", C.c_uint32), ("x_slices", C.c_uint32),
+                ("send_offset", C.POINTER(C.c_uint64)), ("recv_offset", C.POINTER(C.c_uint64)),
+                ("send_counts", C.POINTER(C.c_uint32)), ("recv_counts", C.POINTER(C.c_uint32))]
 
 
 class ProgramParams(C.Structure):
@@ -59,6 +65,7 @@ SIGNATURES = {
     "gt_graph_select_spmv": (C.c_int, [_vp, C.c_int]),
     "gt_graph_vertex_ids": (C.c_int, [_vp, _vp, C.c_uint64]),
     "gt_graph_tile": (C.c_int, [_vp, C.POINTER(TileArrays)]),
+    "gt_graph_exchange_plan": (C.c_int, [_vp, C.POINTER(ExchangePlan)]),
     "gt_graph_free": (C.c_int, [_vp]),
     "gt_program_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(ProgramParams)]),
     "gt_program_initialize": (C.c_int, [_vp]),
@@ -69,6 +76,8 @@ SIGNATURES = {
     "gt_program_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]),
     "gt_program_x": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "gt_program_set_x": (C.c_int, [_vp, _vp]),
+    "gt_program_send": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "gt_program_set_send": (C.c_int, [_vp, _vp]),
     "gt_program_scatter_gather": (C.c_int, [_vp]),
     "gt_program_combine": (C.c_int, [_vp]),
     "gt_program_combine_slice": (C.c_int, [_vp, C.c_uint32]),

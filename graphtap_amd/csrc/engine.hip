@@ -49,6 +49,8 @@ struct gt_program {
     uint8_t *C = nullptr;    // vp:161
     // messages / accumulators (vp:159-160)
     void *x_own = nullptr, *x = nullptr, *y = nullptr;
+    // several ranks: messages of the owned segment's columns [nnzcols] and their per-destination packing (ingest.hip)
+    void *xseg = nullptr, *send_own = nullptr, *send = nullptr;
     uint64_t x_elems = 0, y_elems = 0;
     uint32_t x_bytes = 4, y_bytes = 4;
     unsigned long long *d_active = nullptr;
@@ -71,29 +73,38 @@ struct gt_program {
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
 // scatter_gather_stationary vp:688-708 / _nonstationary vp:711-758 over the owned segment's
 // non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs.
-__global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc, gt_xmap xm) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[gt_xpos(xm, j)] = 1u;  // deg.h:35-37
+__global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[j] = 1u;  // deg.h:35-37
 }
 template <class TX>
 __global__ void k_msg_pr(TX *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
-                         const uint32_t *__restrict__ deg, const double *__restrict__ rank, gt_xmap xm) {
+                         const uint32_t *__restrict__ deg, const double *__restrict__ rank) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j], d = deg[v];
-        x[gt_xpos(xm, j)] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
+        x[j] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
     }
 }
 __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
-                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind, gt_xmap xm) {
+                          const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
         // bfs.h:52-54 (vid), sssp.h:44-46 (distance), cc.h:38-40 (label); inactive -> infinity() vp:749-750
-        x[gt_xpos(xm, j)] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
+        x[j] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
     }
 }
 
-// Deg in _COL_ order (apps/pr.cpp:40-42; vp:1174-1184 with x == 1): y[c] = entries in column c
-__global__ void k_col_counts(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t *__restrict__ y) {
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) y[c] = JA[c + 1] - JA[c];
+// Deg in _COL_ order (apps/pr.cpp:40-42; vp:1174-1184 with x == 1): y[c] = entries in column c. Several ranks: the
+// tile-row's local columns scatter into the global [segment][seg_stride] space (zero-filled by the caller).
+__global__ void k_col_counts(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ loc2glob, uint32_t *__restrict__ y) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) {
+        const uint32_t o = loc2glob ? loc2glob[c] : c;
+        if (o != 0xFFFFFFFFu) y[o] = JA[c + 1] - JA[c];
+    }
+}
+// messages of the owned columns -> send buffer, block (slice k, destination d) after block (ingest.hip: k_send_list)
+template <class TX>
+__global__ void k_pack_send(const TX *__restrict__ xseg, const uint32_t *__restrict__ send_idx, uint64_t n, TX *__restrict__ send) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) send[i] = xseg[send_idx[i]];
 }
 
 // ------------------------------------------------------------------ applicator kernels (K10/K11)
@@ -126,10 +137,10 @@ __global__ void k_apply_deg_row(const uint32_t *__restrict__ y, const uint32_t *
     }
 }
 __global__ void k_apply_deg_col(const uint32_t *__restrict__ y, const uint32_t *__restrict__ JC, uint32_t nc,
-                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C, gt_xmap xm) {
+                                uint32_t *__restrict__ deg, uint8_t *__restrict__ C) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
-        deg[v] = y[gt_xpos(xm, j)]; C[v] = 0;
+        deg[v] = y[j]; C[v] = 0;
     }
 }
 // PageRank in compressed-row space: applicator (pr.h:43-47) of iteration t fused with the messenger
@@ -139,7 +150,7 @@ __global__ void k_apply_deg_col(const uint32_t *__restrict__ y, const uint32_t *
 template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
-                               TX *__restrict__ x, gt_xmap xm, double alpha, double tol, int cf, int last,
+                               TX *__restrict__ x, double alpha, double tol, int cf, int last,
                                unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
@@ -154,7 +165,7 @@ __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restric
         const uint8_t ch = fabs(nv - tmp) > tol;
         C_c[r] = ch;
         act += (ch && !(cf && source));
-        if (!source) { const uint32_t d = deg_c[r]; x[gt_xpos(xm, c)] = (TX)(d ? nv / (double)d : 0.0); }
+        if (!source) { const uint32_t d = deg_c[r]; x[c] = (TX)(d ? nv / (double)d : 0.0); }
     }
     count_active(act, d_active);
 }
@@ -281,7 +292,7 @@ int gt_rmat_generate(void *dev_out, int scale, uint64_t seed, int weighted, uint
 // ---- graph
 int gt_graph_free(gt_graph *g) {
     if (!g) return GT_OK;
-    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C};
+    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     gt_pb_free(g->pb);
     delete g;
@@ -362,7 +373,14 @@ int gt_graph_vertex_ids(const gt_graph *g, uint32_t *host_out, uint64_t count) {
 }
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *a) {
     GT_REQUIRE(g && a, GT_ERR_INVALID, "null argument");
-    a->JA = g->JA; a->IA = g->IA; a->A = g->A; a->JC = g->JC; a->IR = g->IR;
+    a->JA = g->JA; a->IA = g->IA; a->A = g->A; a->JC = g->JC; a->IR = g->IR; a->L2G = g->loc2glob;
+    return GT_OK;
+}
+int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan) {
+    GT_REQUIRE(g && plan, GT_ERR_INVALID, "null argument");
+    plan->nranks = g->info.nranks; plan->x_slices = g->info.x_slices;
+    plan->send_offset = g->send_off.data(); plan->recv_offset = g->recv_off.data();
+    plan->send_counts = g->send_counts.data(); plan->recv_counts = g->recv_counts.data();
     return GT_OK;
 }
 
@@ -374,7 +392,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c};
+    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -404,7 +422,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
     }
     const uint32_t H = g->info.tile_height;
     p->x_elems = g->ncols_total;
-    p->y_elems = (prm->order == GT_COL) ? g->ncols_total : g->info.nnzrows;
+    p->y_elems = (prm->order == GT_COL) ? (uint64_t)g->info.nranks * g->info.seg_stride : g->info.nnzrows;
     bool ok = hipMalloc((void **)&p->s0, (uint64_t)H * 4) == hipSuccess && hipMalloc((void **)&p->C, H) == hipSuccess &&
               hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_bytes) == hipSuccess &&
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
@@ -415,8 +433,11 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
         ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess && hipMalloc((void **)&p->rank_c, nr * 8) == hipSuccess &&
              hipMalloc((void **)&p->deg_c, nr * 4) == hipSuccess && hipMalloc((void **)&p->C_c, nr) == hipSuccess;
     }
+    if (ok && g->info.nranks > 1)
+        ok = hipMalloc(&p->xseg, std::max<uint64_t>(g->info.nnzcols, 1) * p->x_bytes) == hipSuccess &&
+             hipMalloc(&p->send_own, std::max<uint64_t>(g->send_elems, 1) * p->x_bytes) == hipSuccess;
     if (!ok) { gt_program_free(p); gt_set_error("out of device memory for program state"); return GT_ERR_HIP; }
-    p->x = p->x_own;
+    p->x = p->x_own; p->send = p->send_own;
     *out = p;
     return GT_OK;
 }
@@ -465,10 +486,16 @@ static int init_common(gt_program *p) {
             k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
             break;
     }
-    // messages: padding columns are never referenced; give them the semiring's neutral message
-    if (p->x_bytes == 8) k_fill<double><<<grid_for(p->x_elems), TPB, 0, s>>>((double *)p->x, p->x_elems, 0.0);
-    else if (p->x_f32) k_fill<float><<<grid_for(p->x_elems), TPB, 0, s>>>((float *)p->x, p->x_elems, 0.0f);
-    else k_fill<uint32_t><<<grid_for(p->x_elems), TPB, 0, s>>>((uint32_t *)p->x, p->x_elems, p->stationary ? 0u : GT_INF);
+    // messages: padding columns are never referenced; give them (and the exchange buffers) the semiring's neutral message
+    auto neutral = [&](void *buf, uint64_t n) {
+        if (!buf || !n) return;
+        if (p->x_bytes == 8) k_fill<double><<<grid_for(n), TPB, 0, s>>>((double *)buf, n, 0.0);
+        else if (p->x_f32) k_fill<float><<<grid_for(n), TPB, 0, s>>>((float *)buf, n, 0.0f);
+        else k_fill<uint32_t><<<grid_for(n), TPB, 0, s>>>((uint32_t *)buf, n, p->stationary ? 0u : GT_INF);
+    };
+    neutral(p->x, p->x_elems);
+    neutral(p->xseg, g->info.nnzcols);
+    if (p->xseg) neutral(p->send, g->send_elems);
     // accumulators: init_nonstationary fills y with infinity() (vp:625-635); stationary y is zeroed per combine
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
@@ -511,6 +538,19 @@ int gt_program_set_x(gt_program *p, void *dev_ptr) {
     p->x = dev_ptr ? dev_ptr : p->x_own;
     return GT_OK;
 }
+int gt_program_send(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    if (dev_ptr) *dev_ptr = p->xseg ? p->send : nullptr;
+    if (elems) *elems = p->xseg ? p->g->send_elems : 0;
+    if (elem_bytes) *elem_bytes = p->x_bytes;
+    return GT_OK;
+}
+int gt_program_set_send(gt_program *p, void *dev_ptr) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(p->xseg, GT_ERR_STATE, "single-rank programs have no send buffer");
+    p->send = dev_ptr ? dev_ptr : p->send_own;
+    return GT_OK;
+}
 int gt_program_y(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
     if (dev_ptr) *dev_ptr = p->y;
@@ -529,21 +569,25 @@ int gt_program_scatter_gather(gt_program *p) {
     const gt_graph *g = p->g;
     const uint32_t nc = g->info.nnzcols;
     if (p->prm.order == GT_COL || nc == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
-    if (p->x_fresh) { p->x_fresh = false; return GT_OK; }  // the fused PageRank apply already wrote them
-    const gt_xmap xm = gt_xmap_of(g->info, g->info.rank);   // where the owned segment's columns sit in [K][nranks][T]
     hipStream_t s = p->stream;
-    switch (p->prm.kind) {
-        case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x, nc, xm); break;
+    void *xm = p->xseg ? p->xseg : p->x;   // several ranks: the owned columns' messages, packed per destination below
+    if (p->x_fresh) p->x_fresh = false;   // the fused PageRank apply already wrote them
+    else switch (p->prm.kind) {
+        case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, nc); break;
         case GT_PR: {
             int st = pr_sync_state(p); if (st != GT_OK) return st;
-            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)p->x, g->JC, nc, p->s0, p->rank, xm);
-            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)p->x, g->JC, nc, p->s0, p->rank, xm);
+            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)xm, g->JC, nc, p->s0, p->rank);
+            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)xm, g->JC, nc, p->s0, p->rank);
             break;
         }
         default:
-            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)p->x, g->JC, nc, p->C, p->s0,
-                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind, xm);
+            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, g->JC, nc, p->C, p->s0,
+                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
             break;
+    }
+    if (p->xseg && g->send_elems) {
+        if (p->x_bytes == 8) k_pack_send<uint64_t><<<grid_for(g->send_elems), TPB, 0, s>>>((const uint64_t *)p->xseg, g->send_idx, g->send_elems, (uint64_t *)p->send);
+        else k_pack_send<uint32_t><<<grid_for(g->send_elems), TPB, 0, s>>>((const uint32_t *)p->xseg, g->send_idx, g->send_elems, (uint32_t *)p->send);
     }
     GT_HIP(hipGetLastError());
     return GT_OK;
@@ -557,7 +601,8 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
     if (p->converged) return GT_OK;  // vp:1025, 1044: nothing visible happens once converged
     if (p->prm.order == GT_COL) {
         if (hi < K) return GT_OK;
-        k_col_counts<<<grid_for(g->ncols_total), TPB, 0, s>>>(g->JA, g->ncols_total, (uint32_t *)p->y);
+        if (g->loc2glob) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));
+        k_col_counts<<<grid_for(g->ncols_total), TPB, 0, s>>>(g->JA, g->ncols_total, g->loc2glob, (uint32_t *)p->y);
         GT_HIP(hipGetLastError());
         return GT_OK;
     }
@@ -622,19 +667,18 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         case GT_DEG:
             if (p->prm.order == GT_COL) {
                 if (g->info.nnzcols)
-                    k_apply_deg_col<<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)p->y, g->JC, g->info.nnzcols, p->s0, p->C,
-                                                                              gt_xmap_of(g->info, g->info.rank));
+                    k_apply_deg_col<<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)p->y + (uint64_t)g->info.rank * g->info.seg_stride,
+                                                                              g->JC, g->info.nnzcols, p->s0, p->C);
             } else if (nr) k_apply_deg_row<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C);
             break;
         case GT_PR: {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
-            // x may be a caller-installed buffer (multi-rank); the owned segment's columns sit at gt_xpos(xm, .)
-            const gt_xmap xm = gt_xmap_of(g->info, g->info.rank);
+            void *xm = p->xseg ? p->xseg : p->x;   // next iteration's messages of the owned columns
             if (nr && p->x_f32)
-                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)p->x, xm,
+                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active);
             else if (nr)
-                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)p->x, xm,
+                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
                                                                     p->prm.alpha, p->prm.tol, cf, last, d_active);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/graphtap_amd.h"
 
@@ -30,7 +31,7 @@ struct gt_graph {
     gt_graph_info info{};
     gt_graph_flags flags{};
     // TCSC arrays of the tile-row (ds/compressed_column.hpp:287-296)
-    uint32_t *JA = nullptr;   // [ncols_total + 1]
+    uint32_t *JA = nullptr;   // [ncols_total + 1] over the tile-row's column space (see ncols_total)
     uint32_t *IA = nullptr;   // [nnz_local]
     uint32_t *A = nullptr;    // [nnz_local] or null
     uint32_t *JI = nullptr;   // [nnz_local] column id of every entry (edge-parallel kernels)
@@ -41,7 +42,17 @@ struct gt_graph {
     uint32_t *IV = nullptr;   // [H] local vertex -> compressed row
     uint32_t *JV = nullptr;   // [H] local vertex -> compressed col
     uint32_t *R2C = nullptr;  // [nnzrows] compressed row -> compressed col of the same vertex, or ~0u
-    uint32_t ncols_total = 0; // nranks * seg_stride
+    // Column space of the tile-row = index space of the message vector x the SpMV reads. One rank: the compressed
+    // columns themselves (ncols_total = seg_stride). Several ranks: only the columns this tile-row has an entry in,
+    // ordered [slice k][source segment s][ascending compressed column]; slice k occupies [recv_off[k], recv_off[k+1])
+    // (starts are multiples of GT_PB_WINDOW) and its p blocks are exactly what the k-th all-to-all of an iteration
+    // delivers (ingest.hip).
+    uint32_t ncols_total = 0;
+    uint32_t *loc2glob = nullptr;  // [ncols_total] local column -> s * seg_stride + j, ~0u for padding (several ranks)
+    uint32_t *send_idx = nullptr;  // [send_elems] owned compressed column whose message is element i of the send buffer
+    uint64_t send_elems = 0;
+    std::vector<uint32_t> send_counts, recv_counts;  // [K][nranks] elements per block (multiples of 4)
+    std::vector<uint64_t> send_off, recv_off;        // [K + 1] first element of slice k in the send buffer / in x
     // Balanced relabelling for multi-rank graphs (identity when nranks == 1): internal id = (vid * perm_a) & perm_mask,
     // vid = (internal * perm_ainv) & perm_mask. Segments are contiguous ranges of INTERNAL ids.
     uint32_t perm_a = 1, perm_ainv = 1, perm_mask = 0xFFFFFFFFu, nint = 0;  // nint = size of the internal id space
@@ -50,11 +61,6 @@ struct gt_graph {
 };
 
 #define GT_PB_WINDOW 8192u   // columns per phase-1 window (pb.hip); slice widths are multiples of it
-
-// position of compressed column j of segment s in the message vector [K][nranks][T]
-struct gt_xmap { uint32_t T, pT, sT; };   // slice width, nranks * T, s * T
-__host__ __device__ inline uint32_t gt_xpos(const gt_xmap &m, uint32_t j) { const uint32_t k = j / m.T; return k * m.pT + m.sT + (j - k * m.T); }
-inline gt_xmap gt_xmap_of(const gt_graph_info &i, uint32_t seg) { return gt_xmap{i.slice_width, i.nranks * i.slice_width, seg * i.slice_width}; }
 
 // pb.hip
 int gt_pb_build(gt_graph *g);

@@ -40,6 +40,8 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
                          uint32_t nrows, uint32_t perm_a, uint32_t perm_mask, uint32_t H, uint32_t row_lo, uint32_t row_hi,
                          uint64_t *__restrict__ keys, uint32_t *__restrict__ wts,
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
+                         uint8_t *__restrict__ needme /* [span] columns this tile-row reads, or null on one rank */,
+                         uint8_t *__restrict__ needby /* [nranks][H] owned columns read by tile-row d, or null  */,
                          unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
     const int slots = f.directed ? 1 : 2;
     unsigned long long kept = 0, bad = 0, glob = 0;
@@ -54,10 +56,12 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
             if (f.transpose) { uint32_t t = row; row = col; col = t; }
             row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;   // internal ids (identity on one rank)
             rowflag[row] = 1; colflag[col] = 1; glob++;
-            if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; kept++; }
+            if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; kept++; if (needme) needme[col] = 1; }
+            if (needby && col >= row_lo && col < row_hi) needby[(uint64_t)(row / H) * H + (col - row_lo)] = 1;
             if (!f.directed) {
                 rowflag[col] = 1; colflag[row] = 1; glob++;
-                if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; kept++; }
+                if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; kept++; if (needme) needme[row] = 1; }
+                if (needby && row >= row_lo && row < row_hi) needby[(uint64_t)(col / H) * H + (row - row_lo)] = 1;
             }
         }
         keys[e * slots] = k0;
@@ -77,15 +81,68 @@ struct U8ToU32 {
     __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; }
 };
 
-// ---- column ids of the message vector: (segment, compressed column) -> slot in [K][nranks][T]. Done BEFORE the sort
-// so that the entries come out ordered by the id the kernels use (with K > 1 it is not monotone in the vertex id).
-__global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ Scol, uint32_t H, uint32_t T, uint32_t pT) {
+// ---- several ranks: the column space of a tile-row is LOCAL. Rank r keeps only the columns its tile-row has an
+// entry in ("needed" columns, ~47 % of all non-empty columns at p = 8 on R-MAT-26), ordered [slice k][source segment s]
+// [ascending compressed column j]; slice of a column = j / T. Block (k, s) is what rank s sends to rank r in the k-th
+// all-to-all of an iteration, so the receive buffer of that collective IS slice k of the SpMV's message vector.
+struct BlockTab { uint32_t clo, sneed_lo, base; };   // first internal column id of block (k,s); Sneed there; first local id
+
+__device__ __forceinline__ uint32_t local_col(const BlockTab *__restrict__ tab, const uint32_t *__restrict__ Scol,
+                                              const uint32_t *__restrict__ Sneed, uint32_t H, uint32_t T, uint32_t p, uint32_t col) {
+    const uint32_t seg = col / H, j = Scol[col] - Scol[seg * H], k = j / T;
+    const BlockTab b = tab[k * p + seg];
+    return b.base + (Sneed[col] - b.sneed_lo);
+}
+
+// Done BEFORE the sort so that the entries come out ordered by the id the kernels use.
+__global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ Scol, const uint32_t *__restrict__ Sneed,
+                             const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[i];
         if (k == KEY_INVALID) continue;
-        const uint32_t col = (uint32_t)(k >> 32), seg = col / H;
-        const uint32_t c = gt_xpos(gt_xmap{T, pT, seg * T}, Scol[col] - Scol[seg * H]);
+        const uint32_t col = (uint32_t)(k >> 32);
+        const uint32_t c = tab ? local_col(tab, Scol, Sneed, H, T, p, col) : Scol[col];   // one rank: the compressed column id
         keys[i] = ((uint64_t)c << 32) | (uint32_t)k;
+    }
+}
+
+// first internal column id of slice k of segment s: lower bound of Scol[sH] + k*T in Scol[sH .. (s+1)H]
+__global__ void k_slice_bounds(const uint32_t *__restrict__ Scol, uint32_t H, uint32_t T, uint32_t p, uint32_t K, uint32_t *__restrict__ clo) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (K + 1) * p) return;
+    const uint32_t k = t / p, s = t % p;
+    uint64_t lo = (uint64_t)s * H, hi = (uint64_t)(s + 1) * H;
+    if (k < K) {
+        const uint64_t target = (uint64_t)Scol[lo] + (uint64_t)k * T;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (Scol[mid] < target) lo = mid + 1; else hi = mid; }
+    } else lo = hi;
+    clo[t] = (uint32_t)lo;
+}
+__global__ void k_gather_u32(const uint32_t *__restrict__ src, const uint64_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = src[idx[t]];
+}
+// local column -> slot of the global [segment][seg_stride] column space (Degree in _COL_ order all-reduces there)
+__global__ void k_local_to_global(const uint8_t *__restrict__ needme, uint64_t span, const uint32_t *__restrict__ Scol,
+                                  const uint32_t *__restrict__ Sneed, const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p,
+                                  uint32_t S, uint32_t *__restrict__ loc2glob) {
+    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
+        if (!needme[c]) continue;
+        const uint32_t seg = (uint32_t)(c / H);
+        loc2glob[local_col(tab, Scol, Sneed, H, T, p, (uint32_t)c)] = seg * S + (Scol[c] - Scol[(uint64_t)seg * H]);
+    }
+}
+// send list: element i of the send buffer is the message of owned compressed column send_idx[i]
+struct SendTab { uint32_t sby_lo, base; };   // Sby at the first column of block (k,d); first send-buffer element of the block
+__global__ void k_send_list(const uint8_t *__restrict__ needby, const uint32_t *__restrict__ Sby, const uint32_t *__restrict__ Scol,
+                            const SendTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p, uint32_t col_lo, uint32_t *__restrict__ send_idx) {
+    const uint64_t n = (uint64_t)p * H;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        if (!needby[t]) continue;
+        const uint32_t d = (uint32_t)(t / H), i = (uint32_t)(t - (uint64_t)d * H);
+        const uint32_t j = Scol[col_lo + i] - Scol[col_lo], k = j / T;
+        const SendTab b = tab[k * p + d];
+        send_idx[b.base + (Sby[t] - b.sby_lo)] = j;
     }
 }
 
@@ -172,7 +229,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     const uint64_t cap = m * slots;
     hipStream_t s = 0;
 
-    DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp;
+    DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby;
     ING_ALLOC(keys, cap * 8); ING_ALLOC(keys2, cap * 8);
     if (weighted) { ING_ALLOC(wts, cap * 4); ING_ALLOC(wts2, cap * 4); }
     ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
@@ -181,11 +238,18 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     ING_HIP(hipMemsetAsync(rowflag.p, 0, span + 1, s));
     ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
     ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
+    if (p > 1) {
+        ING_ALLOC(needme, span + 1); ING_ALLOC(needby, span + 1);
+        ING_ALLOC(Sneed, (span + 1) * 4); ING_ALLOC(Sby, (span + 1) * 4);
+        ING_HIP(hipMemsetAsync(needme.p, 0, span + 1, s));
+        ING_HIP(hipMemsetAsync(needby.p, 0, span + 1, s));
+    }
 
     if (m)
         k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
+                                             p > 1 ? needme.as<uint8_t>() : nullptr, p > 1 ? needby.as<uint8_t>() : nullptr,
                                              counters.as<unsigned long long>());
     unsigned long long hc[3];
     ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
@@ -209,6 +273,12 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         ING_ALLOC(tmp, tb);
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, rin, Srow.as<uint32_t>(), span + 1, s));
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cin, Scol.as<uint32_t>(), span + 1, s));
+        if (p > 1) {
+            hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> nin(needme.as<const uint8_t>(), U8ToU32());
+            hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> bin(needby.as<const uint8_t>(), U8ToU32());
+            ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nin, Sneed.as<uint32_t>(), span + 1, s));
+            ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, bin, Sby.as<uint32_t>(), span + 1, s));
+        }
     }
     std::vector<uint32_t> segr(p + 1), segc(p + 1);
     for (uint32_t q = 0; q <= p; q++) {
@@ -219,8 +289,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     uint32_t seg_stride = 0;
     for (uint32_t q = 0; q < p; q++) seg_stride = std::max(seg_stride, segc[q + 1] - segc[q]);
     if (seg_stride == 0) seg_stride = 1;
-    // Several ranks: the message vector is cut into K slices [K][nranks][T] so that the exchange of slice k+1 can overlap
-    // phase 1 of slice k; T is a multiple of the phase-1 window so that no window straddles two slices.
+    // Several ranks: the exchange of an iteration is cut into K slices (slice of compressed column j = j / T) so that
+    // the all-to-all of slice k+1 can overlap phase 1 of slice k.
     uint32_t K = 1;
     if (p > 1) {
         const char *e = getenv("GRAPHTAP_X_SLICES");
@@ -228,9 +298,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         if (K < 1) K = 1;
         if (K > 64) K = 64;
     }
-    uint32_t T = (seg_stride + K - 1) / K;
-    if (K > 1) T = (T + GT_PB_WINDOW - 1) / GT_PB_WINDOW * GT_PB_WINDOW;
-    seg_stride = K * T;
+    const uint32_t T = (seg_stride + K - 1) / K;
     g->info.x_slices = K; g->info.slice_width = T;
     g->info.nnzrows = segr[k + 1] - segr[k];
     g->info.nnzcols = segc[k + 1] - segc[k];
@@ -238,9 +306,77 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     g->info.nnzrows_global = segr[p];
     g->info.nnzcols_global = segc[p];
     GT_REQUIRE((uint64_t)p * seg_stride < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "column id space exceeds 32 bits");
-    g->ncols_total = p * seg_stride;
+    g->send_counts.assign((size_t)K * p, 0); g->recv_counts.assign((size_t)K * p, 0);
+    g->send_off.assign(K + 1, 0); g->recv_off.assign(K + 1, 0);
+    DevBuf rtab_d;
+    if (p == 1) {
+        g->ncols_total = seg_stride;
+        g->recv_off[1] = seg_stride;
+    } else {
+        // block (k, s) of the local column space / of the send buffer: boundaries, sizes (rounded up to 4 elements so
+        // that every block of a collective starts 16-byte aligned; both sides round the same count), offsets
+        const uint32_t nb = (K + 1) * p;
+        DevBuf clo_d, idx_d, val_d;
+        ING_ALLOC(clo_d, nb * 4); ING_ALLOC(idx_d, 2ull * nb * 8); ING_ALLOC(val_d, 2ull * nb * 4);
+        k_slice_bounds<<<(nb + TPB - 1) / TPB, TPB, 0, s>>>(Scol.as<uint32_t>(), H, T, p, K, clo_d.as<uint32_t>());
+        std::vector<uint32_t> clo(nb), sneed_at(nb), sby_at(nb);
+        ING_HIP(hipMemcpyAsync(clo.data(), clo_d.p, nb * 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> idx(2ull * nb);
+        for (uint32_t kk = 0; kk <= K; kk++)
+            for (uint32_t q = 0; q < p; q++) {
+                idx[kk * p + q] = clo[kk * p + q];                                               // Sneed at block (kk, source q)
+                idx[nb + kk * p + q] = (uint64_t)q * H + (clo[kk * p + k] - (uint64_t)k * H);    // Sby of destination q at my slice kk
+            }
+        ING_HIP(hipMemcpyAsync(idx_d.p, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, s));
+        k_gather_u32<<<(nb + TPB - 1) / TPB, TPB, 0, s>>>(Sneed.as<uint32_t>(), idx_d.as<uint64_t>(), nb, val_d.as<uint32_t>());
+        k_gather_u32<<<(nb + TPB - 1) / TPB, TPB, 0, s>>>(Sby.as<uint32_t>(), idx_d.as<uint64_t>() + nb, nb, val_d.as<uint32_t>() + nb);
+        ING_HIP(hipMemcpyAsync(sneed_at.data(), val_d.p, nb * 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipMemcpyAsync(sby_at.data(), val_d.as<uint32_t>() + nb, nb * 4, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipStreamSynchronize(s));
+        std::vector<BlockTab> rtab((size_t)K * p);
+        std::vector<SendTab> stab((size_t)K * p);
+        uint64_t xo = 0, so = 0;
+        for (uint32_t kk = 0; kk < K; kk++) {
+            g->recv_off[kk] = xo; g->send_off[kk] = so;
+            for (uint32_t q = 0; q < p; q++) {
+                const uint32_t nrecv = (sneed_at[(kk + 1) * p + q] - sneed_at[kk * p + q] + 3u) & ~3u;
+                const uint32_t nsend = (sby_at[(kk + 1) * p + q] - sby_at[kk * p + q] + 3u) & ~3u;
+                GT_REQUIRE(xo + nrecv < 0xFFFFFFF0ull && so + nsend < 0xFFFFFFF0ull, GT_ERR_UNSUPPORTED, "exchange buffers exceed 32-bit indexing");
+                rtab[kk * p + q] = BlockTab{clo[kk * p + q], sneed_at[kk * p + q], (uint32_t)xo};
+                stab[kk * p + q] = SendTab{sby_at[kk * p + q], (uint32_t)so};
+                g->recv_counts[kk * p + q] = nrecv; g->send_counts[kk * p + q] = nsend;
+                xo += nrecv; so += nsend;
+            }
+            xo = (xo + GT_PB_WINDOW - 1) / GT_PB_WINDOW * GT_PB_WINDOW;   // no phase-1 window straddles two slices
+        }
+        if (xo == 0) xo = GT_PB_WINDOW;
+        g->recv_off[K] = xo; g->send_off[K] = so;
+        g->ncols_total = (uint32_t)xo;
+        g->send_elems = so;
+        ING_ALLOC(rtab_d, rtab.size() * sizeof(BlockTab));
+        ING_HIP(hipMemcpyAsync(rtab_d.p, rtab.data(), rtab.size() * sizeof(BlockTab), hipMemcpyHostToDevice, s));
+        DevBuf stab_d;
+        ING_ALLOC(stab_d, stab.size() * sizeof(SendTab));
+        ING_HIP(hipMemcpyAsync(stab_d.p, stab.data(), stab.size() * sizeof(SendTab), hipMemcpyHostToDevice, s));
+        if (hipMalloc((void **)&g->loc2glob, (uint64_t)g->ncols_total * 4) != hipSuccess ||
+            hipMalloc((void **)&g->send_idx, std::max<uint64_t>(so, 1) * 4) != hipSuccess) {
+            gt_set_error("ingest: out of device memory for the exchange tables");
+            return GT_ERR_HIP;
+        }
+        ING_HIP(hipMemsetAsync(g->loc2glob, 0xFF, (uint64_t)g->ncols_total * 4, s));
+        ING_HIP(hipMemsetAsync(g->send_idx, 0, std::max<uint64_t>(so, 1) * 4, s));
+        k_local_to_global<<<grid_for(span), TPB, 0, s>>>(needme.as<uint8_t>(), span, Scol.as<uint32_t>(), Sneed.as<uint32_t>(),
+                                                         rtab_d.as<BlockTab>(), H, T, p, seg_stride, g->loc2glob);
+        k_send_list<<<grid_for(span), TPB, 0, s>>>(needby.as<uint8_t>(), Sby.as<uint32_t>(), Scol.as<uint32_t>(), stab_d.as<SendTab>(),
+                                                   H, T, p, row_lo, g->send_idx);
+        ING_HIP(hipStreamSynchronize(s));   // stab / idx scratch go out of scope here
+    }
+    g->info.ncols_local = g->ncols_total;
+    g->info.send_elems = (uint32_t)g->send_elems;
 
-    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), H, g->info.slice_width, p * g->info.slice_width);
+    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), p > 1 ? Sneed.as<uint32_t>() : nullptr,
+                                                        p > 1 ? rtab_d.as<BlockTab>() : nullptr, H, T, p);
     // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
     // so that the first copy of a duplicate (row,col) carries its minimum weight. Invalid keys sink
     // to the end. Radix sort is stable.

@@ -661,15 +661,14 @@ int gt_pb_build(gt_graph *g) {
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
     if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
     PB_MALLOC(pb->chunk_active, (uint64_t)nchunks * 4); PB_MALLOC(pb->active_prefix, (uint64_t)(nchunks + 1) * 4);
-    {   // chunks are in column order and no window straddles a slice (slice_width is a multiple of W when K > 1)
+    {   // chunks are in column order and no window straddles a slice (slice k starts at recv_off[k], a multiple of W)
         const uint32_t K = g->info.x_slices;
-        const uint64_t pT = (uint64_t)g->info.nranks * g->info.slice_width;
         std::vector<uint32_t> hcol(nchunks);
         PB_HIP(hipMemcpy(hcol.data(), pb->ccol0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
         pb->slice_chunk.assign(K + 1, nchunks);
         pb->slice_chunk[0] = 0;
         for (uint32_t k = 1; k < K; k++)
-            pb->slice_chunk[k] = (uint32_t)(std::lower_bound(hcol.begin(), hcol.end(), (uint32_t)(k * pT)) - hcol.begin());
+            pb->slice_chunk[k] = (uint32_t)(std::lower_bound(hcol.begin(), hcol.end(), (uint32_t)g->recv_off[k]) - hcol.begin());
     }
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());

@@ -5,8 +5,11 @@ Partitioning (the a=1 b=p alternative, which is what the reference it
 p=2): rank k owns vertex segment k (height H = nrows/p + 1, src/mat/matrix.hpp:193) and tile-row k
 of the p x p grid. Every iteration
 
-  scatter_gather  rank k computes the messages x_k of ITS non-empty columns   (vp:688-758)
-  exchange        all-gather of the p segments of x, in K slices                (replaces the
+  scatter_gather  rank k computes the messages of ITS non-empty columns and packs, per
+                  destination d, the ones tile-row d has an entry for         (vp:688-758)
+  exchange        K all-to-alls (slice by slice) deliver to every rank exactly the
+                  columns its tile-row reads -- 47 % of an all-gather's volume at 8 ranks on
+                  R-MAT-26, all 7 xGMI links of a GPU busy at once (replaces the
                   MPI_Ibcast down column groups, vp:843-862 / 970-1013)
   combine         local SpMV over tile-row k; y_k is complete, no row-group reduce is needed
                   (the reference's M6/M7 Isend/Irecv, vp:1083-1111, disappears with a = 1)
@@ -28,13 +31,18 @@ def _staged(t):
     return dist.get_backend() == "gloo" and t.is_cuda
 
 
-def all_gather_segments(x, mine, group=None):
+def exchange_slice(x, send, plan, k, group=None, async_op=False):
+    """Slice k of the message exchange (gt_graph_exchange_plan): block d of the send buffer's slice k goes to rank d,
+    whose x receives it as block `me` of ITS slice k. Returns the work handle when async_op."""
+    send_off, recv_off, send_counts, recv_counts = plan
+    out = x[recv_off[k]:recv_off[k] + sum(recv_counts[k])]
+    inp = send[send_off[k]:send_off[k] + sum(send_counts[k])]
     if _staged(x):
-        h = x.cpu(); m = mine.cpu().clone()
-        dist.all_gather_into_tensor(h, m, group=group)
-        x.copy_(h)
-    else:
-        dist.all_gather_into_tensor(x, mine, group=group)
+        ho, hi = out.cpu(), inp.cpu()
+        dist.all_to_all_single(ho, hi, recv_counts[k], send_counts[k], group=group)
+        out.copy_(ho)
+        return None
+    return dist.all_to_all_single(out, inp, recv_counts[k], send_counts[k], group=group, async_op=async_op)
 
 
 def all_reduce_sum(t, group=None):
@@ -47,29 +55,28 @@ def all_reduce_sum(t, group=None):
 def run(engine, iters, group=None):
     """Vertex_Program::execute (vp:408-441) across ranks. Returns (iterations, converged).
 
-    The message vector is [K][p][T] (K = engine.x_slices slices of width T of every rank's segment). With K > 1
-    the K all-gathers of an iteration are issued back to back (async_op) on RCCL's stream and the local SpMV is
-    driven slice by slice: phase 1 of slice k runs while slices k+1.. are still in flight."""
+    With K = engine.x_slices > 1 the K all-to-alls of an iteration are issued back to back (async_op) on RCCL's
+    stream and the local SpMV is driven slice by slice: phase 1 of slice k runs while slices k+1.. are in flight."""
     check = (iters == 0)
-    p, k = engine.nranks, engine.rank
+    p = engine.nranks
     K = getattr(engine, "x_slices", 1)
-    x = engine.x_tensor()               # [K * p * T] messages
-    T = x.numel() // (K * p)
-    slices = [x[s * p * T:(s + 1) * p * T] for s in range(K)]
-    mine = [sl[k * T:(k + 1) * T] for sl in slices]
-    pipelined = p > 1 and K > 1 and engine.needs_x_exchange and not _staged(x) and hasattr(engine, "combine_slice")
+    x = engine.x_tensor()               # the message vector the local SpMV reads
+    exchange = p > 1 and engine.needs_x_exchange
+    if exchange:
+        send, plan = engine.send_tensor(), engine.exchange_plan()
+    pipelined = exchange and K > 1 and not _staged(x) and hasattr(engine, "combine_slice")
     converged = False
     while True:
         engine.scatter_gather()
         if pipelined:
-            works = [dist.all_gather_into_tensor(slices[s], mine[s], group=group, async_op=True) for s in range(K)]
+            works = [exchange_slice(x, send, plan, s, group, async_op=True) for s in range(K)]
             for s in range(K):
                 works[s].wait()          # the compute stream waits for slice s only
                 engine.combine_slice(s)
         else:
-            if p > 1 and engine.needs_x_exchange:
+            if exchange:
                 for s in range(K):
-                    all_gather_segments(slices[s], mine[s], group=group)
+                    exchange_slice(x, send, plan, s, group)
             engine.combine()
         if p > 1 and engine.column_accumulators:
             all_reduce_sum(engine.y_tensor(), group=group)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import GraphFlags, GraphInfo, GraphTapError, TileArrays, check, lib
+from ._lib import ExchangePlan, GraphFlags, GraphInfo, GraphTapError, TileArrays, check, lib
 
 # Tiling_type (src/mat/tiling.hpp:13-16) / Compression_type (src/ds/compressed_column.hpp)
 _2D_, _2DT_ = 0, 1
@@ -130,7 +130,7 @@ class Graph:
     def tile_to_host(self):
         """Copies the owned tile-row's TCSC arrays to numpy (tests compare them with the oracle's)."""
         t, i = self.tile(), self.info
-        ncols_total = i.nranks * i.seg_stride
+        ncols_total = i.ncols_local
 
         def grab(ptr, n):
             a = np.zeros(n, np.uint32)
@@ -138,7 +138,17 @@ class Graph:
                 check(lib().gt_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, n * 4))
             return a
         return dict(JA=grab(t.JA, ncols_total + 1), IA=grab(t.IA, i.nnz_local),
-                    A=grab(t.A, i.nnz_local) if t.A else None, JC=grab(t.JC, i.nnzcols), IR=grab(t.IR, i.nnzrows))
+                    A=grab(t.A, i.nnz_local) if t.A else None, JC=grab(t.JC, i.nnzcols), IR=grab(t.IR, i.nnzrows),
+                    L2G=grab(t.L2G, ncols_total) if t.L2G else None)
+
+    def exchange_plan(self):
+        """gt_graph_exchange_plan as python lists: (send_offset[K+1], recv_offset[K+1], send_counts[K][p], recv_counts[K][p])."""
+        pl = ExchangePlan()
+        check(lib().gt_graph_exchange_plan(self._h, C.byref(pl)))
+        K, p = pl.x_slices, pl.nranks
+        return ([int(pl.send_offset[k]) for k in range(K + 1)], [int(pl.recv_offset[k]) for k in range(K + 1)],
+                [[int(pl.send_counts[k * p + d]) for d in range(p)] for k in range(K)],
+                [[int(pl.recv_counts[k * p + d]) for d in range(p)] for k in range(K)])
 
     # -- Graph::free (graph.hpp:76-81)
     def free(self):

@@ -41,7 +41,7 @@ class _HipEngine:
         self.x_slices, self.slice_width = i.x_slices, i.slice_width
         self.column_accumulators = (prog.ordering_type == _COL_)
         self.needs_x_exchange = not self.column_accumulators
-        self._x = self._y = None
+        self._x = self._y = self._send = None
 
     def _tensor(self, getter):
         import torch
@@ -55,21 +55,36 @@ class _HipEngine:
             return "<f8" if width == 8 else "<f4"
         return "<i4"
 
+    def _installed(self, getter, setter):
+        """A torch allocation with the engine buffer's contents, installed into the engine, so that RCCL sees
+        ordinary caching-allocator memory."""
+        import torch
+        ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
+        check(getter(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
+        if not n.value:
+            return torch.zeros(0, dtype={"<f8": torch.float64, "<f4": torch.float32, "<i4": torch.int32}[self._typestr(w.value)], device="cuda")
+        t = torch.as_tensor(_CudaArray(ptr.value, n.value, self._typestr(w.value)), device="cuda").clone()
+        check(setter(self.prog._h, C.c_void_p(t.data_ptr())))
+        return t
+
     def x_tensor(self):
-        """The message vector handed to the collective. For a multi-rank run it is a torch allocation
-        installed into the engine (gt_program_set_x), so RCCL sees ordinary caching-allocator memory;
-        the single-rank loopback tests view the engine's own buffer."""
+        """The message vector the local SpMV reads (receive side of the exchange on several ranks); the
+        single-rank case views the engine's own buffer."""
         if self._x is None:
             if self.nranks > 1:
-                import torch
-                ptr, n, w = C.c_void_p(), C.c_uint64(), C.c_uint32()
-                check(lib().gt_program_x(self.prog._h, C.byref(ptr), C.byref(n), C.byref(w)))
-                own = torch.as_tensor(_CudaArray(ptr.value, n.value, self._typestr(w.value)), device="cuda")
-                self._x = own.clone()            # keeps whatever initialize() put there
-                check(lib().gt_program_set_x(self.prog._h, C.c_void_p(self._x.data_ptr())))
+                self._x = self._installed(lib().gt_program_x, lib().gt_program_set_x)
             else:
                 self._x = self._tensor(lib().gt_program_x)
         return self._x
+
+    def send_tensor(self):
+        """Several ranks: the per-destination packing of the owned columns' messages (gt_program_send)."""
+        if self._send is None:
+            self._send = self._installed(lib().gt_program_send, lib().gt_program_set_send)
+        return self._send
+
+    def exchange_plan(self):
+        return self.prog.G.exchange_plan()
 
     def y_tensor(self):
         if self._y is None:

@@ -79,26 +79,50 @@ typedef struct gt_graph_info {
     uint32_t rank, nranks;  /* this handle holds tile-row `rank` of the p x p grid */
     uint32_t nnzrows;       /* non-empty rows of the owned segment                */
     uint32_t nnzcols;       /* non-empty columns of the owned segment             */
-    uint32_t seg_stride;    /* message slots per segment (>= every segment's nnzcols): x has nranks*seg_stride elements */
+    uint32_t seg_stride;    /* S = the largest nnzcols over all segments: the global column space [segment][S] that
+                               Degree in _COL_ order accumulates (and all-reduces) in has nranks*S slots          */
     uint64_t nnz_local;     /* stored entries in this tile-row                    */
     uint64_t nnz_global;    /* stored entries over all tile-rows (TEPS denominator) */
     uint64_t nnzrows_global, nnzcols_global;
     int32_t weighted;
     uint32_t regular, source_rows, sink_cols; /* owned-segment class counts (matrix.hpp:1125-1144) */
-    uint32_t x_slices;      /* K: the message vector is [K][nranks][slice_width] (K = 1 on one rank)      */
-    uint32_t slice_width;   /* T = seg_stride / K; compressed column j of segment s sits at
-                               (j / T) * nranks * T + s * T + j % T                                      */
+    uint32_t x_slices;      /* K: the exchange of an iteration runs in K slices (K = 1 on one rank)       */
+    uint32_t slice_width;   /* T = ceil(S / K): compressed column j of any segment travels in slice j / T  */
+    uint32_t ncols_local;   /* elements of the message vector x this handle's SpMV reads: S on one rank; on several
+                               ranks only the columns the tile-row has an entry in, see gt_graph_exchange_plan */
+    uint32_t send_elems;    /* elements of the send buffer (0 on one rank)                                 */
 } gt_graph_info;
 
 /* Device pointers to the owned tile-row in TCSC form (ds/compressed_column.hpp:287-296).
-   Column ids are [segment][compressed col]: c = s * seg_stride + j. */
+   Column ids index the message vector x (ncols_local of them): the compressed columns on one rank, the tile-row's
+   needed columns in exchange order on several (gt_graph_exchange_plan). */
 typedef struct gt_tile_arrays {
-    const uint32_t *JA; /* [nranks*seg_stride + 1] column pointers              */
+    const uint32_t *JA; /* [ncols_local + 1] column pointers                    */
     const uint32_t *IA; /* [nnz_local] compressed row ids                       */
     const uint32_t *A;  /* [nnz_local] weights, or NULL                         */
     const uint32_t *JC; /* [nnzcols]  compressed col -> segment-local vertex id */
     const uint32_t *IR; /* [nnzrows]  compressed row -> segment-local vertex id */
+    const uint32_t *L2G;/* [ncols_local] several ranks: column -> s * seg_stride + j (segment s, compressed
+                           column j), UINT32_MAX for padding; NULL on one rank   */
 } gt_tile_arrays;
+
+/* The exchange of the message vector between ranks, replacing the reference's MPI_Ibcast of every x segment down its
+ * column group (vp:843-862, 970-1013). A tile-row only reads the columns it has an entry in (47 % of all non-empty
+ * columns at 8 ranks on R-MAT-26), so instead of all-gathering whole segments every rank SENDS to rank d just the
+ * messages tile-row d needs: K all-to-alls per iteration (slice k of every segment in the k-th).
+ *   send buffer (gt_program_send): slice k starts at send_offset[k]; its nranks blocks, destination-major, hold
+ *     send_counts[k*nranks + d] elements for rank d;
+ *   message vector x (gt_program_x): slice k starts at recv_offset[k]; its nranks blocks, source-major, hold
+ *     recv_counts[k*nranks + s] elements from rank s.
+ * Counts are multiples of 4 elements; recv_counts[k][s] on rank r equals send_counts[k][r] on rank s. The arrays
+ * live in the graph handle (host memory) until gt_graph_free. */
+typedef struct gt_exchange_plan {
+    uint32_t nranks, x_slices;
+    const uint64_t *send_offset; /* [x_slices + 1] */
+    const uint64_t *recv_offset; /* [x_slices + 1] */
+    const uint32_t *send_counts; /* [x_slices * nranks] */
+    const uint32_t *recv_counts; /* [x_slices * nranks] */
+} gt_exchange_plan;
 
 typedef struct gt_program_params {
     int32_t kind;        /* gt_kind                                               */
@@ -158,6 +182,7 @@ int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
  * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
 int gt_graph_select_spmv(gt_graph *g, int variant);
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
+int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan);
 /* Original vertex id of the first `count` (<= tile_height) state slots of this handle, UINT32_MAX for a padding
  * slot. On one rank slot i is vertex i (the reference's layout, vp:1805-1808). On several ranks the owned
  * segment is a contiguous range of a hashed internal id space (load balance under degree skew: tile-row 0 of 8
@@ -189,14 +214,18 @@ int gt_program_enable_timing(gt_program *p, int on);
 int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int reset);
 
 /* phase level, for the multi-GPU driver (graphtap_amd/dist.py) ------------
- * x is one device buffer of nranks*seg_stride messages laid out [x_slices][nranks][slice_width] (f64 for PageRank -- f32
- * when the graph's SpMV variant is GT_SPMV_PB_F32MSG at program creation -- u32
- * otherwise; gt_program_x reports the element width); with one slice segment s is [s*seg_stride, (s+1)*seg_stride). The engine owns a
- * default buffer; a caller that exchanges through its own allocation (a torch
- * tensor handed to RCCL) installs it with gt_program_set_x. */
+ * x is the message vector the local SpMV reads: ncols_local elements (f64 for PageRank -- f32 when the graph's SpMV
+ * variant is GT_SPMV_PB_F32MSG at program creation -- u32 otherwise; gt_program_x reports the element width). On one
+ * rank it is written by scatter_gather directly. On several ranks scatter_gather fills the SEND buffer
+ * (gt_program_send, send_elems elements of the same type) and the driver moves it into every rank's x with the K
+ * all-to-alls of gt_graph_exchange_plan. The engine owns default buffers; a caller that exchanges through its own
+ * allocations (torch tensors handed to RCCL) installs them with gt_program_set_x / gt_program_set_send. */
 int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
 int gt_program_set_x(gt_program *p, void *dev_ptr);
-/* scatter_gather(), vp:639-758 without the broadcast: fills the OWNED segment of x */
+int gt_program_send(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
+int gt_program_set_send(gt_program *p, void *dev_ptr);
+/* scatter_gather(), vp:639-758 without the broadcast: the messages of the OWNED segment's columns (into x on one
+ * rank, packed per destination into the send buffer on several) */
 int gt_program_scatter_gather(gt_program *p);
 /* combine(), vp:1017-1113 for the local tile-row (all column segments of x must be current) */
 int gt_program_combine(gt_program *p);
@@ -211,9 +240,9 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active);
 /* the `converged` tail of execute(), vp:425-428 (only PageRank under GT_TCSC_CF is affected) */
 int gt_program_finish_converged(gt_program *p);
 int gt_program_iteration(const gt_program *p, uint32_t *iteration);
-/* In GT_COL order (Deg in apps/pr.cpp) the accumulators live in column space and every
- * rank holds a partial sum; the driver sums them across ranks (the reference's
- * row-group reduce M6, vp:1083-1111) before apply. */
+/* In GT_COL order (Deg in apps/pr.cpp) the accumulators live in the GLOBAL column space [segment][seg_stride]
+ * (nranks*seg_stride elements) and every rank holds a partial sum; the driver sums them across ranks (the
+ * reference's row-group reduce M6, vp:1083-1111) before apply. */
 int gt_program_y(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
 
 /* V, vp:61: copies `count` (<= tile_height) entries of the owned segment to the host */
@@ -227,7 +256,7 @@ int gt_program_free(gt_program *p);
 
 /* ---- kernel-level seam: spmv_stationary / spmv_nonstationary -----------
  * (vp:1116-1327, 1438-1506) y = A (x) x over the handle's tile-row, device pointers.
- * x: nranks*seg_stride elements, y: nnzrows elements, both of the semiring's type;
+ * x: ncols_local elements, y: nnzrows elements, both of the semiring's type;
  * y is accumulated into (the caller zero/INF-fills it). Columns whose message is
  * GT_INF are skipped under the two min semirings (vp:1492). */
 int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream);

@@ -28,12 +28,23 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert _lib.lib().gt_abi_version() == 1
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offset of the last member of every struct of the header, as gcc sees them, against the ctypes mirror"""
+    import subprocess
     from graphtap_amd import _lib
-    assert C.sizeof(_lib.GraphFlags) == 20
-    assert C.sizeof(_lib.GraphInfo) == 4 * 8 + 8 * 4 + 4 * 4 + 8
-    assert C.sizeof(_lib.ProgramParams) == 32
-    assert C.sizeof(_lib.ExecStats) == 56
+    pairs = [("gt_graph_flags", _lib.GraphFlags, "parallel_edges"), ("gt_graph_info", _lib.GraphInfo, "send_elems"),
+             ("gt_tile_arrays", _lib.TileArrays, "L2G"), ("gt_exchange_plan", _lib.ExchangePlan, "recv_counts"),
+             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "apply_ms")]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "graphtap_amd.h"\nint main(void){' +
+                   "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, m) for c, _, m in pairs) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for (cname, cls, member), line in zip(pairs, lines):
+        size, off = map(int, line.split())
+        assert C.sizeof(cls) == size and getattr(cls, member).offset == off, cname
+    assert C.sizeof(_lib.GraphInfo) == 96 and C.sizeof(_lib.ExecStats) == 56
 
 
 def test_no_cpu_fallback_without_a_gpu():

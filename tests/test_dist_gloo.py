@@ -2,8 +2,8 @@
 
 The driver is the code that runs on the GPU box with backend "nccl" (= RCCL); here the tile engine it
 drives is a small numpy model of one rank's tile-row built from the CPU oracle's TCSC arrays (test
-infrastructure), so the partition arithmetic (H = nrows/p + 1, [segment][seg_stride] message layout,
-padding), the exchange pattern and the convergence all-reduce are exercised across real processes.
+infrastructure), so the partition arithmetic (H = nrows/p + 1, the needed-columns exchange plan with its K
+slices and padded blocks), the all-to-all pattern and the convergence all-reduce are exercised across real processes.
 Results must equal the reference's golden vectors: integer programs bit for bit, PageRank to 1e-6."""
 import os
 import socket
@@ -40,16 +40,43 @@ class NumpyTileEngine:
         rowflag[rows_v] = True; colflag[cols_v] = True
         Srow = np.concatenate([[0], np.cumsum(rowflag)]); Scol = np.concatenate([[0], np.cumsum(colflag)])
         nnzcols_seg = [Scol[(s + 1) * H] - Scol[s * H] for s in range(p)]
-        # message vector [K][p][T]: slot of compressed column j of segment s = (j // T) * p * T + s * T + j % T
+        # exchange plan (include/graphtap_amd.h, gt_exchange_plan): slice of compressed column j = j // T; rank r's x
+        # holds, slice after slice and source segment after source segment, the columns tile-row r has an entry in
         self.x_slices = K = x_slices
-        self.T = T = -(-max(max(nnzcols_seg), 1) // K)
-        self.seg_stride = stride = K * T
+        self.S = S = max(max(nnzcols_seg), 1)
+        self.T = T = -(-S // K)
+        PAD, ALIGN = 4, 8          # block sizes round up to 4 elements, slice starts to a "window" (8 here)
+        owner = rows_v // H
+        cseg_all = cols_v // H
+        j_all = Scol[cols_v] - Scol[cseg_all * H]
+
+        def need(r, s):            # sorted compressed columns of segment s that tile-row r reads
+            return np.unique(j_all[(owner == r) & (cseg_all == s)])
+        up = lambda n, a: -(-n // a) * a
         lo = rank * H
-        mine = (rows_v // H) == rank
+        mine = owner == rank
         self.r = (Srow[rows_v[mine]] - Srow[lo]).astype(np.int64)            # local compressed row
-        cseg = cols_v[mine] // H
-        j = Scol[cols_v[mine]] - Scol[cseg * H]
-        self.c = ((j // T) * p * T + cseg * T + j % T).astype(np.int64)
+        cseg, j = cseg_all[mine], j_all[mine]
+        self.c = np.zeros(j.size, np.int64)                                   # local column of every entry
+        self.recv_off, self.send_off, self.recv_counts, self.send_counts = [], [], [], []
+        xo = so = 0
+        send_idx = []
+        for k in range(K):
+            self.recv_off.append(xo); self.send_off.append(so)
+            rc, sc = [], []
+            for s_ in range(p):
+                nd = need(rank, s_); nd = nd[nd // T == k]
+                sel = (cseg == s_) & (j // T == k)
+                self.c[sel] = xo + np.searchsorted(nd, j[sel])
+                rc.append(up(nd.size, PAD)); xo += rc[-1]
+                out = need(s_, rank); out = out[out // T == k]               # what destination s_ reads of MY columns
+                sc.append(up(out.size, PAD)); so += sc[-1]
+                send_idx += list(out) + [0] * (sc[-1] - out.size)
+            self.recv_counts.append(rc); self.send_counts.append(sc)
+            xo = up(xo, ALIGN)
+        self.recv_off.append(max(xo, ALIGN)); self.send_off.append(so)
+        self.send_idx = np.array(send_idx, np.int64)
+        self.cg = (cseg * S + j).astype(np.int64)                             # global [segment][S] column (Degree, _COL_)
         self.w = w[mine] if w is not None else None
         self.nnz_local = int(mine.sum())
         self.I = rowflag[lo:lo + H]; self.J = colflag[lo:lo + H]
@@ -60,8 +87,10 @@ class NumpyTileEngine:
         self.iteration = 0
         self.converged = False
         fp = np.float64 if kind == "pr" else np.int32
-        self.x = np.zeros(p * stride, fp)
-        self.y = np.zeros(p * stride if order_col else self.nr, fp)
+        self.x = np.zeros(self.recv_off[-1], fp)
+        self.send = np.zeros(max(so, 1), fp)[:so]
+        self.xseg = np.zeros(max(self.nc, 1), fp)
+        self.y = np.zeros(p * S if order_col else self.nr, fp)
         vid = lo + np.arange(H)
         if kind == "deg":
             self.degree = np.zeros(H, np.int64); self.C = np.ones(H, bool)
@@ -78,19 +107,17 @@ class NumpyTileEngine:
 
     def x_tensor(self): return torch.from_numpy(self.x)
     def y_tensor(self): return torch.from_numpy(self.y)
-
-    def _own(self):
-        j = np.arange(self.nc)
-        return (j // self.T) * self.nranks * self.T + self.rank * self.T + j % self.T
+    def send_tensor(self): return torch.from_numpy(self.send)
+    def exchange_plan(self): return self.send_off, self.recv_off, self.send_counts, self.recv_counts
 
     def scatter_gather(self):
-        if self.column_accumulators: return
-        s = self._own()
+        if self.column_accumulators or self.nc == 0: return
         v = self.JC
-        if self.kind == "deg": self.x[s] = 1
-        elif self.kind == "pr": self.x[s] = np.where(self.degree[v] > 0, self.rank_[v] / np.maximum(self.degree[v], 1), 0.0)
-        elif self.kind == "bfs": self.x[s] = np.where(self.C[v], self.vid[v], INF)
-        else: self.x[s] = np.where(self.C[v], self.s0[v], INF)
+        if self.kind == "deg": self.xseg[:] = 1
+        elif self.kind == "pr": self.xseg[:] = np.where(self.degree[v] > 0, self.rank_[v] / np.maximum(self.degree[v], 1), 0.0)
+        elif self.kind == "bfs": self.xseg[:] = np.where(self.C[v], self.vid[v], INF)
+        else: self.xseg[:] = np.where(self.C[v], self.s0[v], INF)
+        self.send[:] = self.xseg[self.send_idx]
 
     def combine(self):
         for k in range(self.x_slices): self.combine_slice(k)
@@ -99,10 +126,9 @@ class NumpyTileEngine:
         """entries whose column lies in slice k of the message vector (only that slice of x is guaranteed current)"""
         if self.converged: return
         if self.column_accumulators:
-            if k == self.x_slices - 1: self.y[:] = np.bincount(self.c, minlength=self.y.size)
+            if k == self.x_slices - 1: self.y[:] = np.bincount(self.cg, minlength=self.y.size)
             return
-        pT = self.nranks * self.T
-        sel = (self.c // pT) == k
+        sel = (self.c >= self.recv_off[k]) & (self.c < self.recv_off[k + 1])
         if self.kind in ("deg", "pr"):
             if k == 0: self.y[:] = 0
             np.add.at(self.y, self.r[sel], self.x[self.c[sel]])
@@ -120,7 +146,7 @@ class NumpyTileEngine:
         if self.iteration == 0: self.C[~self.I] = False
         if self.kind == "deg":
             if self.column_accumulators:
-                self.degree[self.JC] = self.y[self._own()]; self.C[self.JC] = False
+                self.degree[self.JC] = self.y[self.rank * self.S + np.arange(self.nc)]; self.C[self.JC] = False
             else:
                 self.degree[v] = self.y; self.C[v] = False
         elif self.kind == "pr":

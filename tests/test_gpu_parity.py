@@ -268,15 +268,15 @@ def test_midsize_rmat_against_oracle(gt, O, scale, seed):
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 @pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
 def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, variant, monkeypatch):
-    """Every rank's tile-row on the same GPU, with the all-gather of x done by device copies: checks
-    the p-rank data layout (H = nrows/p + 1, [segment][seg_stride] columns, owned-segment state)
+    """Every rank's tile-row on the same GPU, with the all-to-alls of x done by device copies: checks
+    the p-rank data layout (H = nrows/p + 1, needed-columns exchange plan, owned-segment state)
     of the engine without RCCL. BFS labels must equal the reference's np=1 run bit for bit;
     PageRank within 1e-6 (the reference's own np>1 runs differ from np=1 by fp association too)."""
     import torch
     from graphtap_amd import dist as gdist
     from graphtap_amd.vertex_program import _HipEngine
     monkeypatch.setenv("GRAPHTAP_SPMV", variant)   # read by gt_graph_build
-    monkeypatch.setenv("GRAPHTAP_X_SLICES", str({"pb": 4, "pb_f32msg": 2, "edge": 1}[variant]))   # K of the [K][p][T] message layout
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str({"pb": 4, "pb_f32msg": 2, "edge": 1}[variant]))   # K slices of the exchange
     c = load_case(name); nv = c["num_vertices"]; n = nv + 1
 
     class Loopback:
@@ -291,18 +291,20 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
 
     def lockstep(progs, engs, iters):
         check = iters == 0
-        stride = engs[0].seg_stride
         while True:
             for e_ in engs: e_.scatter_gather()
-            if engs[0].needs_x_exchange:   # the all-gather of every slice [K][p][T], by device copies
-                xs = [e_.x_tensor() for e_ in engs]
-                K, T = engs[0].x_slices, engs[0].slice_width
-                assert K * T == stride and xs[0].numel() == nranks * stride
-                for k in range(K):
-                    for r, xr in enumerate(xs):
-                        a = k * nranks * T + r * T
-                        for q, xq in enumerate(xs):
-                            if q != r: xq[a:a + T].copy_(xr[a:a + T])
+            if engs[0].needs_x_exchange:   # the K all-to-alls of gt_graph_exchange_plan, by device copies
+                xs = [e_.x_tensor() for e_ in engs]; sends = [e_.send_tensor() for e_ in engs]
+                plans = [e_.exchange_plan() for e_ in engs]
+                for k in range(engs[0].x_slices):
+                    for r in range(nranks):          # source
+                        so, _, sc, _ = plans[r]
+                        for d in range(nranks):      # destination
+                            _, ro, _, rc = plans[d]
+                            assert sc[k][d] == rc[k][r] and sc[k][d] % 4 == 0
+                            a = so[k] + sum(sc[k][:d]); b = ro[k] + sum(rc[k][:r])
+                            assert b + rc[k][r] <= ro[k + 1]
+                            xs[d][b:b + rc[k][r]].copy_(sends[r][a:a + sc[k][d]])
             if engs[0].x_slices > 1 and (len(progs) + engs[0].iteration) % 2 == 0:   # exercise the sliced entry point too
                 for k in range(engs[0].x_slices):
                     for e_ in engs: e_.combine_slice(k)
@@ -412,8 +414,8 @@ def test_pagerank_rmat22_properties(gt):
 def test_propagation_blocking_equals_edge_kernel(gt, scale, nranks, rank):
     """The production kernel pair (pb.hip) against the edge-parallel baseline on the same tile-row, for
     every semiring: integer semirings bit-exact, f64 sums to 1e-12 (both re-associate). Covers several
-    row bins, split bins (atomic merge), partial windows and the padded [segment][seg_stride] column
-    space of a multi-rank tile-row."""
+    row bins, split bins (atomic merge), partial windows and the local (needed-columns) column space
+    of a multi-rank tile-row."""
     from graphtap_amd.rmat import rmat_edges
     L = gt._lib.lib()
     nv = 1 << scale
@@ -436,7 +438,7 @@ def test_propagation_blocking_equals_edge_kernel(gt, scale, nranks, rank):
 
     G = gt.Graph(weighted=True)
     G.load_edges(w, nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=rank, nranks=nranks)
-    nx, ny = G.info.nranks * G.info.seg_stride, G.info.nnzrows
+    nx, ny = G.info.ncols_local, G.info.nnzrows
     x = rng.rand(nx); y0 = rng.rand(ny)
     a, b = run(G, gt._lib.GT_PLUS_F64, x, y0)
     assert np.allclose(a, b, rtol=1e-12, atol=0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-rank compute time of the N-GPU PageRank step, measured on ONE GPU: builds tile-row `rank` of `nranks`
 of the R-MAT graph and runs the three local phases (scatter_gather, combine, apply) without the exchange.
-The missing term of a real N-GPU step is the all-gather of x (RCCL), which a 1-GPU box cannot run.
+The missing term of a real N-GPU step is the exchange of x (K all-to-alls over RCCL), which a 1-GPU box cannot run;
+the bytes this rank would receive and send per step are reported.
   python tools/bench_tilerow.py --scale 26 --nranks 8 --rank 0"""
 import argparse, ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,4 +35,5 @@ _lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
 i = G.info
 print(json.dumps({"scale": a.scale, "rank": a.rank, "nranks": a.nranks, "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
                   "seg_stride": int(i.seg_stride), "ms_per_step_compute_only": dt * 1e3 / a.steps, "spmv_ms": ms.value / max(n.value, 1),
-                  "x_exchange_bytes_f32": int(i.nranks * i.seg_stride * 4)}))
+                  "ncols_local": int(i.ncols_local), "recv_bytes_f32": int(sum(map(sum, G.exchange_plan()[3])) * 4),
+                  "send_bytes_f32": int(i.send_elems * 4), "allgather_bytes_f32": int(i.nnzcols_global * 4)}))
