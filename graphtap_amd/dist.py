@@ -45,6 +45,20 @@ def exchange_slice(x, send, plan, k, group=None, async_op=False):
     return dist.all_to_all_single(out, inp, recv_counts[k], send_counts[k], group=group, async_op=async_op)
 
 
+def verify_plan(plan, device, group=None):
+    """Once per engine: every rank tells every peer how much it is going to send per slice; a disagreement with the
+    receiver's own plan (which would make the all-to-alls hang or scribble) is reported instead."""
+    _, _, send_counts, recv_counts = plan
+    K, p = len(send_counts), len(send_counts[0])
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    mine = torch.tensor([[send_counts[k][d] for k in range(K)] for d in range(p)], dtype=torch.int64, device=dev)   # [dest][slice]
+    theirs = torch.empty_like(mine)
+    dist.all_to_all_single(theirs, mine, group=group)                                                               # [source][slice]
+    want = torch.tensor([[recv_counts[k][s] for k in range(K)] for s in range(p)], dtype=torch.int64, device=dev)
+    if not torch.equal(theirs, want):
+        raise RuntimeError("exchange plan mismatch between ranks (were the graphs built from the same edge list and flags?)")
+
+
 def all_reduce_sum(t, group=None):
     if _staged(t):
         h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
@@ -64,6 +78,9 @@ def run(engine, iters, group=None):
     exchange = p > 1 and engine.needs_x_exchange
     if exchange:
         send, plan = engine.send_tensor(), engine.exchange_plan()
+        if not getattr(engine, "_plan_verified", False):
+            verify_plan(plan, x.device, group)
+            engine._plan_verified = True
     pipelined = exchange and K > 1 and not _staged(x) and hasattr(engine, "combine_slice")
     converged = False
     while True:

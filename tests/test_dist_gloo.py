@@ -214,3 +214,30 @@ def test_driver_over_gloo_matches_reference(tmp_path, case, world, known_answers
     assert parts[0]["sssp_iters"] == ka["np1_sssp"]["iterations"]
     assert parts[0]["cc_iters"] == ka["np1_cc"]["iterations"]
     assert sum(p["nnz_local"] for p in parts) == len(c["edges"])   # PR keeps every record (pr.cpp:28-30)
+
+
+def _plan_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphtap_amd import dist as gdist
+    # K = 2 slices, p = 2: rank 0 sends 4/8 (slice 0/1) to rank 1, rank 1 sends 12/0 to rank 0; own blocks 4/4
+    send = {0: [[4, 4], [4, 8]], 1: [[12, 4], [0, 4]]}[rank]
+    recv = {0: [[4, 12], [4, 0]], 1: [[4, 4], [8, 4]]}[rank]
+    gdist.verify_plan(([0, 8, 20], [0, 16, 24], send, recv), "cpu")            # consistent: passes
+    bad = [row[:] for row in recv]
+    if rank == 1: bad[1][0] = 4                                                  # rank 1 expects 4 where rank 0 sends 8
+    try:
+        gdist.verify_plan(([0, 8, 20], [0, 16, 24], send, bad), "cpu"); raised = False
+    except RuntimeError as e:
+        raised = "exchange plan mismatch" in str(e)
+    flags = [None] * world
+    dist.all_gather_object(flags, raised)
+    if rank == 0: torch.save(flags, out)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_exchange_plan_mismatch_is_reported(tmp_path):
+    out = str(tmp_path / "flags.pt")
+    mp.spawn(_plan_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out, weights_only=False) == [False, True]
