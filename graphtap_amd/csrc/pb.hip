@@ -39,6 +39,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 
 #include "gt_internal.h"
@@ -286,20 +287,21 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
-                                                           uint32_t chunk0) {
-    __shared__ TV xwin[W + 64];
-    __shared__ TV stage[P1_THREADS / 64][256];   // per-wave compaction row for the outputs of one 256-entry group
-    const uint32_t c = chunk0 + blockIdx.x;
+                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0) {
+    __shared__ TV xwin[W + 1];
+    struct alignas(sizeof(TV) == 8 ? 16 : 8) SV { TV v; uint32_t k; };
+    __shared__ SV stage[P1_THREADS / 64][256 + 64];   // per wave: (value, k-slot) of the outputs of one 256-entry group + 64 dump slots
+    const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     {   // stage the window: all loads of a lane in flight together
-        constexpr int PER = W / P1_THREADS;
+        constexpr int PER = (W + P1_THREADS - 1) / P1_THREADS;
         TX t[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; t[i] = (j < wn) ? x[col0 + j] : TX(0); }
 #pragma unroll
-        for (int i = 0; i < PER; i++) xwin[threadIdx.x + i * P1_THREADS] = (TV)t[i];
+        for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * P1_THREADS; if (j < W) xwin[j] = (TV)t[i]; }
         if (threadIdx.x == 0) xwin[PADCOL] = neutral;
         if constexpr (IS_MIN) {
             // Activity filtering (the reference's sparse path, vp:754-784, 1475-1489, at window granularity): a chunk
@@ -320,6 +322,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes 0..lane
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 4;   // 256-entry groups in flight per wave
     const uint32_t gend = (q1c + 63) >> 6;
@@ -354,49 +357,49 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // group-end bits of the quad and the number of outputs of this lane
             const uint32_t e0 = live && (lc[u].c[0] & GEND), e1 = live && (lc[u].c[1] & GEND), e2 = live && (lc[u].c[2] & GEND),
                            e3 = live && (lc[u].c[3] & GEND);
-            const uint32_t n = e0 + e1 + e2 + e3;
-            // exclusive prefix of n over the wave without touching the LDS pipe: one ballot + mbcnt per group-end bit
+            // exclusive prefix of the output count over the wave without touching the LDS pipe: one ballot + mbcnt per bit
             auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
             const uint32_t pex = below(__ballot(e0)) + below(__ballot(e1)) + below(__ballot(e2)) + below(__ballot(e3));
-            const uint32_t p = pex + n;   // inclusive
-            // segmented combine over the quad: one output per (quad, row) group, compacted into the wave's LDS
-            // staging row at [pex, pex + n) so that the stores below are fully coalesced
+            const uint32_t p = pex + e0 + e1 + e2 + e3;   // inclusive
+            // k-slot of this lane's outputs: its run is the group's first run (k-slot k0 = dword 0 of the group record) or
+            // starts at the nh-th run head of the group (dword nh, nh = 1..6; KSTART beyond). A quad never straddles runs.
+            const bool head = live && lane != 0 && (lc[u].c[0] & HEAD) != 0;
+            const uint64_t Hb = __ballot(head);
+            const uint32_t nh = below(Hb) + (head ? 1u : 0u);                       // run heads at or before this lane
+            const uint64_t hm = Hb & lane_le;
+            const int hl = hm ? 63 - __clzll((unsigned long long)hm) : 0;            // lane of my run's head
+            uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nh < 7 ? nh : 0u) << 2), (int)gw[u]);
+            if (__ballot(nh >= 7)) {   // rare: seven or more run heads in one 256-entry group
+                if (nh >= 7) base = KSTART[__builtin_amdgcn_readlane(gw[u], 7) + nh];
+            }
+            const uint32_t off = nh ? (uint32_t)__builtin_amdgcn_ds_bpermute(hl << 2, (int)pex) : 0u;
+            const uint32_t delta = base - off;                                       // k-slot = position in the wave's row + delta
+            // segmented combine over the quad: one output per (quad, row) group, compacted together with its k-slot into
+            // the wave's LDS row at [pex, p) so that the stores below are coalesced runs; entries that do not end a group
+            // write to a per-lane dump slot instead of branching
             TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
                v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
-            TV *st = stage[wave];
+            SV *st = stage[wave];
+            const uint32_t dump = 256 + lane;
             __builtin_amdgcn_wave_barrier();
             TV acc = v0;
-            if (e0) st[pex] = acc;
-            acc = e0 ? v1 : comb(acc, v1);
-            if (e1) st[pex + e0] = acc;
-            acc = e1 ? v2 : comb(acc, v2);
-            if (e2) st[pex + e0 + e1] = acc;
-            acc = e2 ? v3 : comb(acc, v3);
-            if (e3) st[pex + e0 + e1 + e2] = acc;
+            uint32_t pos = pex;
+            st[e0 ? pos : dump] = SV{acc, pos + delta};
+            acc = e0 ? v1 : comb(acc, v1); pos += e0;
+            st[e1 ? pos : dump] = SV{acc, pos + delta};
+            acc = e1 ? v2 : comb(acc, v2); pos += e1;
+            st[e2 ? pos : dump] = SV{acc, pos + delta};
+            acc = e2 ? v3 : comb(acc, v3); pos += e2;
+            st[e3 ? pos : dump] = SV{acc, pos + delta};
             __builtin_amdgcn_wave_barrier();
             // this chunk's quads are a contiguous lane range -> a contiguous range [mlo, mhi) of the compacted outputs
             const uint64_t M = __ballot(mine);
             if (M != 0) {
                 const int l0 = __ffsll((unsigned long long)M) - 1, l1 = 63 - __clzll((unsigned long long)M);
                 const uint32_t mlo = __builtin_amdgcn_readlane(pex, l0), mhi = __builtin_amdgcn_readlane(p, l1);
-                const uint64_t H = __ballot(live && (lc[u].c[0] & HEAD) != 0) & ~1ull;   // run heads in lanes 1..63
-                // dword 0 of the group record = k-slot of the group's first output; dword i (1..6) = k-slot of the i-th
-                // run head; dword 7 = run of lane 0 (for the rare groups with seven or more heads)
-                const uint32_t k0 = __builtin_amdgcn_readlane(gw[u], 0);
-                for (uint32_t m = mlo + lane; m < mhi; m += 64) {
-                    uint32_t base = k0, off = 0;
-                    uint64_t Hm = H;
-                    int i = 0;
-                    while (Hm) {   // wave-uniform loop over the run heads of the group (usually 0-2)
-                        const int hl = __ffsll((unsigned long long)Hm) - 1;
-                        Hm &= Hm - 1; i++;
-                        const uint32_t Bi = __builtin_amdgcn_readlane(pex, hl);
-                        const uint32_t KSi = (i < 7) ? __builtin_amdgcn_readlane(gw[u], i) : KSTART[__builtin_amdgcn_readlane(gw[u], 7) + i];
-                        if (m >= Bi) { base = KSi; off = Bi; }
-                    }
-                    VAL[base + (m - off)] = st[m];
-                }
+#pragma nounroll
+                for (uint32_t m = mlo + lane; m < mhi; m += 64) { const SV t = st[m]; VAL[t.k] = t.v; }   // at most 4 trips
             }
         }
         g0 = gn;
@@ -471,6 +474,7 @@ struct gt_pb {
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
+    uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice, largest chunk first
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
     int val_kind = 0;          // 1: f32 messages of an f64 sum, 2: f64, 3: u32
@@ -479,7 +483,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -626,6 +630,25 @@ int gt_pb_build(gt_graph *g) {
     DevBuf binoff; PB_ALLOC(binoff, (uint64_t)(pb->nbins + 1) * 4);
     k_bin_offsets<<<grid_for(pb->nbins + 1), TPB, 0, s>>>(runbin_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun, nout, pb->nbins, binoff.as<uint32_t>());
     k_chunk_ranges<<<grid_for(nchunks), TPB, 0, s>>>(runkey.as<uint32_t>(), nrun, binbits, pvstart.as<uint32_t>(), nchunks, pb->cv0, pb->cv1);
+    if (getenv("GRAPHTAP_PB_STATS")) {   // phase-1 load balance: list scheduling of the chunks on 512 resident workgroups
+        std::vector<uint32_t> a(nchunks), b(nchunks);
+        PB_HIP(hipMemcpy(a.data(), pb->cv0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        PB_HIP(hipMemcpy(b.data(), pb->cv1, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        std::vector<double> cost(nchunks);
+        double sum = 0, mx = 0;
+        for (uint32_t c = 0; c < nchunks; c++) { cost[c] = (double)(b[c] - a[c]) + 16384.0; sum += cost[c]; mx = std::max(mx, cost[c]); }
+        auto makespan = [&](const std::vector<double> &cs) {
+            std::vector<double> slot(512, 0.0);
+            std::make_heap(slot.begin(), slot.end(), std::greater<double>());
+            double end = 0;
+            for (double c : cs) { std::pop_heap(slot.begin(), slot.end(), std::greater<double>()); slot.back() += c; end = std::max(end, slot.back()); std::push_heap(slot.begin(), slot.end(), std::greater<double>()); }
+            return end;
+        };
+        const double inorder = makespan(cost);
+        std::sort(cost.begin(), cost.end(), std::greater<double>());
+        fprintf(stderr, "[pb] phase-1 balance on 512 slots (cost = entries + 16K): ideal %.0f, in order %.0f (x%.3f), largest first %.0f (x%.3f), largest chunk %.0f\n",
+                sum / 512, inorder, inorder / (sum / 512), makespan(cost), makespan(cost) / (sum / 512), mx);
+    }
 
     // static streams: v-order pads read LDS slot PADCOL (the neutral message); k-order pads target row 0 of the bin
     const uint64_t ngroups = ((uint64_t)np + 255) / 256;
@@ -669,6 +692,20 @@ int gt_pb_build(gt_graph *g) {
         pb->slice_chunk[0] = 0;
         for (uint32_t k = 1; k < K; k++)
             pb->slice_chunk[k] = (uint32_t)(std::lower_bound(hcol.begin(), hcol.end(), (uint32_t)g->recv_off[k]) - hcol.begin());
+        // Launch order. Chunk sizes are skewed (a window of hub columns fills its 2^20-entry cap, the mean chunk of
+        // R-MAT-26 holds 0.29 M entries) and a chunk costs time in proportion to its entries: in column order the 512
+        // resident workgroups finish 33 % later than an even split would (list-scheduling model, [pb] stats);
+        // largest-first brings that to 1 %.
+        std::vector<uint32_t> a(nchunks), b(nchunks), ord(nchunks);
+        PB_HIP(hipMemcpy(a.data(), pb->cv0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        PB_HIP(hipMemcpy(b.data(), pb->cv1, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < nchunks; c++) ord[c] = c;
+        if (!getenv("GRAPHTAP_PB_COLUMN_ORDER"))
+            for (uint32_t k = 0; k < K; k++)
+                std::stable_sort(ord.begin() + pb->slice_chunk[k], ord.begin() + pb->slice_chunk[k + 1],
+                                 [&](uint32_t x, uint32_t y) { return b[x] - a[x] > b[y] - a[y]; });
+        PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
+        PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
     }
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
@@ -694,7 +731,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     if (c1 > c0)
         k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
             pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
-            (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, c0);
+            (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, pb->launch_order, c0);
     if (slice_hi >= K) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
         k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
