@@ -169,6 +169,17 @@ __global__ void k_bin_offsets(const uint32_t *__restrict__ bins_sorted, const ui
         bin_off[b] = lo < nrun ? kscan[lo] : np;
     }
 }
+// the last run of every chunk takes the pads that round the chunk's padded entry count up to a multiple of 256
+__global__ void k_align_chunks(const uint32_t *__restrict__ runkey, uint32_t nrun, int binbits, const uint32_t *__restrict__ pvstart,
+                               uint32_t *__restrict__ lenpad) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nrun; s += gridDim.x * blockDim.x) {
+        const uint32_t c = runkey[s] >> binbits;
+        if (s + 1 < nrun && (runkey[s + 1] >> binbits) == c) continue;
+        const uint32_t a = lower_bound_u32(runkey, nrun, c << binbits);
+        const uint32_t total = pvstart[s + 1] - pvstart[a];
+        lenpad[s] += (256u - (total & 255u)) & 255u;
+    }
+}
 // chunk c covers the runs whose key >> binbits == c (keys are sorted): its padded v-range
 __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nrun, int binbits, const uint32_t *__restrict__ pvstart,
                                uint32_t nchunks, uint32_t *__restrict__ cv0, uint32_t *__restrict__ cv1) {
@@ -283,7 +294,7 @@ struct alignas(16) W4 { uint32_t w[4]; };
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
-                                                           const uint32_t *__restrict__ ccol0, uint32_t ncols, uint32_t nquads,
+                                                           const uint32_t *__restrict__ ccol0, uint32_t ncols,
                                                            const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
@@ -292,7 +303,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     struct alignas(sizeof(TV) == 8 ? 16 : 8) SV { TV v; uint32_t k; };
     __shared__ SV stage[P1_THREADS / 64][256 + 64];   // per wave: (value, k-slot) of the outputs of one 256-entry group + 64 dump slots
     const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
-    const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range
+    const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)
     const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     {   // stage the window: all loads of a lane in flight together
@@ -325,21 +336,19 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes 0..lane
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 4;   // 256-entry groups in flight per wave
-    const uint32_t gend = (q1c + 63) >> 6;
+    const uint32_t gend = q1c >> 6;   // chunk ranges are multiples of 256 entries = 64 quads (k_align_chunks)
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
-    // Groups are aligned to 64 quads in v-space; a group at a chunk border is visited by both chunks,
-    // each storing only its own quads. Software pipeline: the loads of trip t+1 are issued BEFORE the
-    // stores of trip t, so a wave does not wait on its own store acknowledgements (vmcnt retires in order).
+    // Software pipeline: the loads of trip t+1 are issued BEFORE the stores of trip t, so a wave does not wait
+    // on its own store acknowledgements (vmcnt retires in order).
     C4 lc[U], nlc[U]; uint32_t gw[U], ngw[U]; W4 w[U], nw[U];
     auto issue_loads = [&](uint32_t g0, C4 (&olc)[U], uint32_t (&ogw)[U], W4 (&ow)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
             const uint32_t q = g * 64 + lane;
-            const uint32_t qc = q < nquads ? q : nquads - 1;
-            olc[u] = LCOL4[qc];                                   // 8 B/lane
+            olc[u] = LCOL4[q];                                    // 8 B/lane
             ogw[u] = Gw[(uint64_t)g * 8 + (lane & 7)];            // lane i holds dword i & 7 of the 32-byte group record
-            if constexpr (WEIGHTED) ow[u] = WT4[qc]; else ow[u] = W4{{0, 0, 0, 0}};
+            if constexpr (WEIGHTED) ow[u] = WT4[q]; else ow[u] = W4{{0, 0, 0, 0}};
         }
     };
     uint32_t g0 = (q0c >> 6) + wave * U;
@@ -349,21 +358,15 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         if (gn < gend) issue_loads(gn, nlc, ngw, nw);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t g = g0 + u;
-            if (g >= gend) break;
-            const uint32_t q = g * 64 + lane;
-            const bool live = q < nquads;
-            const bool mine = (q >= q0c && q < q1c);
-            // group-end bits of the quad and the number of outputs of this lane
-            const uint32_t e0 = live && (lc[u].c[0] & GEND), e1 = live && (lc[u].c[1] & GEND), e2 = live && (lc[u].c[2] & GEND),
-                           e3 = live && (lc[u].c[3] & GEND);
+            if (g0 + u >= gend) break;
+            // group-end bits of the quad
+            const bool e0 = (lc[u].c[0] & GEND) != 0, e1 = (lc[u].c[1] & GEND) != 0, e2 = (lc[u].c[2] & GEND) != 0, e3 = (lc[u].c[3] & GEND) != 0;
             // exclusive prefix of the output count over the wave without touching the LDS pipe: one ballot + mbcnt per bit
             auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
             const uint32_t pex = below(__ballot(e0)) + below(__ballot(e1)) + below(__ballot(e2)) + below(__ballot(e3));
-            const uint32_t p = pex + e0 + e1 + e2 + e3;   // inclusive
             // k-slot of this lane's outputs: its run is the group's first run (k-slot k0 = dword 0 of the group record) or
             // starts at the nh-th run head of the group (dword nh, nh = 1..6; KSTART beyond). A quad never straddles runs.
-            const bool head = live && lane != 0 && (lc[u].c[0] & HEAD) != 0;
+            const bool head = lane != 0 && (lc[u].c[0] & HEAD) != 0;
             const uint64_t Hb = __ballot(head);
             const uint32_t nh = below(Hb) + (head ? 1u : 0u);                       // run heads at or before this lane
             const uint64_t hm = Hb & lane_le;
@@ -386,21 +389,17 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             TV acc = v0;
             uint32_t pos = pex;
             st[e0 ? pos : dump] = SV{acc, pos + delta};
-            acc = e0 ? v1 : comb(acc, v1); pos += e0;
+            acc = e0 ? v1 : comb(acc, v1); pos += e0 ? 1u : 0u;
             st[e1 ? pos : dump] = SV{acc, pos + delta};
-            acc = e1 ? v2 : comb(acc, v2); pos += e1;
+            acc = e1 ? v2 : comb(acc, v2); pos += e1 ? 1u : 0u;
             st[e2 ? pos : dump] = SV{acc, pos + delta};
-            acc = e2 ? v3 : comb(acc, v3); pos += e2;
+            acc = e2 ? v3 : comb(acc, v3); pos += e2 ? 1u : 0u;
             st[e3 ? pos : dump] = SV{acc, pos + delta};
+            pos += e3 ? 1u : 0u;
             __builtin_amdgcn_wave_barrier();
-            // this chunk's quads are a contiguous lane range -> a contiguous range [mlo, mhi) of the compacted outputs
-            const uint64_t M = __ballot(mine);
-            if (M != 0) {
-                const int l0 = __ffsll((unsigned long long)M) - 1, l1 = 63 - __clzll((unsigned long long)M);
-                const uint32_t mlo = __builtin_amdgcn_readlane(pex, l0), mhi = __builtin_amdgcn_readlane(p, l1);
+            const uint32_t total = __builtin_amdgcn_readlane(pos, 63);   // outputs of the group
 #pragma nounroll
-                for (uint32_t m = mlo + lane; m < mhi; m += 64) { const SV t = st[m]; VAL[t.k] = t.v; }   // at most 4 trips
-            }
+            for (uint32_t m = lane; m < total; m += 64) { const SV t = st[m]; VAL[t.k] = t.v; }   // at most 4 trips
         }
         g0 = gn;
 #pragma unroll
@@ -578,11 +577,15 @@ int gt_pb_build(gt_graph *g) {
     PB_HIP(hipMemsetAsync(lenpad.as<uint32_t>() + nrun, 0, 4, s));
     k_run_lens<<<grid_for(nrun), TPB, 0, s>>>(vstart.as<uint32_t>(), runkey.as<uint32_t>(), nrun, nnz, binmask, len.as<uint32_t>(),
                                               lenpad.as<uint32_t>(), runbin.as<uint32_t>());
+    PB_SCAN_EXCL(lenpad.as<uint32_t>(), pvstart.as<uint32_t>(), nrun + 1);
+    // every chunk's padded v-range becomes a multiple of 256 entries (extra pads after its last run), so that a
+    // 256-entry group of phase 1 never straddles two chunks
+    k_align_chunks<<<grid_for(nrun), TPB, 0, s>>>(runkey.as<uint32_t>(), nrun, binbits, pvstart.as<uint32_t>(), lenpad.as<uint32_t>());
     PB_SCAN_EXCL(lenpad.as<uint32_t>(), pvstart.as<uint32_t>(), nrun + 1);   // pvstart[nrun] = padded total
     uint32_t np = 0;
     PB_HIP(hipMemcpy(&np, pvstart.as<uint32_t>() + nrun, 4, hipMemcpyDeviceToHost));
     {
-        uint64_t chk = (uint64_t)nnz + 3ull * nrun;
+        uint64_t chk = (uint64_t)nnz + 3ull * nrun + 255ull * nchunks;
         if (chk >= 0xFFFFFFF0ull) { gt_set_error("pb build: padded entry count exceeds 32 bits"); gt_pb_free(pb); return GT_ERR_UNSUPPORTED; }
     }
     pb->np = np;
@@ -730,7 +733,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
     if (c1 > c0)
         k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
-            pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, pb->np >> 2, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
+            pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
             (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, pb->launch_order, c0);
     if (slice_hi >= K) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
