@@ -372,8 +372,19 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const uint64_t hm = Hb & lane_le;
             const int hl = hm ? 63 - __clzll((unsigned long long)hm) : 0;            // lane of my run's head
             uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nh < 7 ? nh : 0u) << 2), (int)gw[u]);
-            if (__ballot(nh >= 7)) {   // rare: seven or more run heads in one 256-entry group
-                if (nh >= 7) base = KSTART[__builtin_amdgcn_readlane(gw[u], 7) + nh];
+            if (__popcll((unsigned long long)Hb) >= 7) {
+                // rare: seven or more run heads in one 256-entry group. Walks the heads beyond the sixth with wave-uniform
+                // (scalar) loads: a vector load here would put a vmcnt(0) wait -- prefetches and stores included -- into
+                // every group of the common path
+                const uint32_t s0 = __builtin_amdgcn_readlane(gw[u], 7);
+                uint64_t Hm = Hb;
+                for (int i = 0; i < 6; i++) Hm &= Hm - 1;
+                for (uint32_t i = 7; Hm; i++) {
+                    const uint32_t hlane = (uint32_t)__ffsll((unsigned long long)Hm) - 1;
+                    Hm &= Hm - 1;
+                    const uint32_t ks = KSTART[s0 + i];
+                    if (lane >= hlane) base = ks;
+                }
             }
             const uint32_t off = nh ? (uint32_t)__builtin_amdgcn_ds_bpermute(hl << 2, (int)pex) : 0u;
             const uint32_t delta = base - off;                                       // k-slot = position in the wave's row + delta
