@@ -684,12 +684,15 @@ int gt_pb_build(gt_graph *g) {
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
     std::vector<BinWork> work;
+    const uint64_t epw = getenv("GRAPHTAP_PB_EPW") ? (1ull << atoi(getenv("GRAPHTAP_PB_EPW"))) : EPW;
     for (uint32_t b = 0; b < pb->nbins; b++) {
         uint64_t n = hoff[b + 1] - hoff[b];
         if (!n) continue;
-        uint32_t parts = (uint32_t)((n + EPW - 1) / EPW);
+        uint32_t parts = (uint32_t)((n + epw - 1) / epw);
+        const uint64_t per = ((n + parts - 1) / parts + 255) & ~255ull;   // equal parts (whole 256-slot blocks)
         for (uint32_t i = 0; i < parts; i++) {
-            uint64_t a = hoff[b] + (uint64_t)i * EPW, e = std::min<uint64_t>(a + EPW, hoff[b + 1]);
+            uint64_t a = std::min<uint64_t>(hoff[b] + (uint64_t)i * per, hoff[b + 1]), e = std::min<uint64_t>(a + per, hoff[b + 1]);
+            if (a == e) continue;
             work.push_back(BinWork{b, (uint32_t)a, (uint32_t)e, parts == 1 ? 1u : 0u, 0u, 0u, 0u, 0u});
         }
     }
