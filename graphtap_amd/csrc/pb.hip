@@ -9,7 +9,10 @@
 //            x[col0 .. col0+W) are staged in LDS (coalesced load), then for every entry, in
 //            (chunk, row-bin) order, VAL[k] = x[col] (+ w) is written at the entry's slot k of the
 //            row-bin-major value stream. A lane handles a QUAD of four consecutive entries: one 8-byte
-//            load of window-local column ids, four LDS reads, up to four 4/8-byte stores (one per row group).
+//            load of window-local column ids, four LDS reads; the (value, k-slot) pairs of a 256-entry group
+//            are compacted through a per-wave LDS row (ballot/mbcnt prefix, branch-free) and stored as
+//            coalesced runs. The kernel is written around its instruction count: it was issue-bound, not
+//            memory-bound, before.
 //   phase 2  "gather"    one workgroup per ROW BIN (R = 16384 consecutive compressed rows; heavy
 //            bins are split by entry count): the bin's partial accumulators live in LDS (R x F =
 //            128 KiB for f64), the bin's slice of VAL and of the static bin-local row ids LROW is
