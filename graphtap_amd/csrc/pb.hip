@@ -64,6 +64,10 @@ static uint32_t ch_default(uint32_t nnz) {
 constexpr uint32_t EPW = 1u << 18;     // (padded) entries per phase-2 workgroup
 constexpr int P1_THREADS = 1024;
 constexpr int P2_THREADS = 1024;
+#ifndef GT_P2_U
+#define GT_P2_U 2
+#endif
+constexpr int P2_U = GT_P2_U;            // quads in flight per lane in phase 2
 constexpr uint16_t HEAD = 0x8000;
 constexpr uint16_t COLMASK = 0x3FFF;
 constexpr uint16_t GEND = 0x4000;      // last entry of its (quad, row) group
@@ -439,18 +443,20 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     for (uint32_t i = threadIdx.x; i < R; i += P2_THREADS) acc[i] = neutral;
     __syncthreads();
     // 4 consecutive entries per lane per load (16-byte VAL loads for f32/u32 streams, 2 x 16 B for f64;
-    // 8-byte LROW loads), two quads in flight per lane; every range is a multiple of 4 (padded runs).
+    // 8-byte LROW loads), P2_U quads in flight per lane (one workgroup per CU: the loads in flight have to cover
+    // the HBM latency by themselves); every range is a multiple of 4 (padded runs).
     const uint32_t qb = wk.k1 >> 2;
     uint32_t q = (wk.k0 >> 2) + threadIdx.x;
-    for (; q + P2_THREADS < qb; q += 2 * P2_THREADS) {
-        const C4 r0 = LROW4[q], r1 = LROW4[q + P2_THREADS];
-        const V4<TV> a0 = VAL4[q], a1 = VAL4[q + P2_THREADS];
+    for (; q + (P2_U - 1) * P2_THREADS < qb; q += P2_U * P2_THREADS) {
+        C4 r[P2_U]; V4<TV> a[P2_U];
 #pragma unroll
-        for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
+        for (int u = 0; u < P2_U; u++) { r[u] = LROW4[q + u * P2_THREADS]; a[u] = VAL4[q + u * P2_THREADS]; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r1.c[j], (T)a1.a[j]);
+        for (int u = 0; u < P2_U; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r[u].c[j], (T)a[u].a[j]);
     }
-    if (q < qb) {
+    for (; q < qb; q += P2_THREADS) {
         const C4 r0 = LROW4[q]; const V4<TV> a0 = VAL4[q];
 #pragma unroll
         for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
