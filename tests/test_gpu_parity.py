@@ -264,6 +264,58 @@ def test_midsize_rmat_against_oracle(gt, O, scale, seed):
 
 
 # ------------------------------------------------------------------------------- multi-rank layout on one GPU
+def _loopback_engines(progs):
+    from graphtap_amd.vertex_program import _HipEngine
+    for p in progs:
+        if not p._already_initialized: p.initialize()
+    return [_HipEngine(p) for p in progs]
+
+
+def _loopback_lockstep(progs, engs, iters):
+    """dist.run for the p engines living in this process: its collectives replaced by device copies"""
+    nranks = len(engs)
+    check = iters == 0
+    while True:
+        for e_ in engs: e_.scatter_gather()
+        if engs[0].needs_x_exchange:   # the K all-to-alls of gt_graph_exchange_plan, by device copies
+            xs = [e_.x_tensor() for e_ in engs]; sends = [e_.send_tensor() for e_ in engs]
+            plans = [e_.exchange_plan() for e_ in engs]
+            for k in range(engs[0].x_slices):
+                for r in range(nranks):          # source
+                    so, _, sc, _ = plans[r]
+                    for d in range(nranks):      # destination
+                        _, ro, _, rc = plans[d]
+                        assert sc[k][d] == rc[k][r] and sc[k][d] % 4 == 0
+                        a = so[k] + sum(sc[k][:d]); b = ro[k] + sum(rc[k][:r])
+                        assert b + rc[k][r] <= ro[k + 1]
+                        xs[d][b:b + rc[k][r]].copy_(sends[r][a:a + sc[k][d]])
+        if engs[0].x_slices > 1 and (len(progs) + engs[0].iteration) % 2 == 0:   # exercise the sliced entry point too
+            for k in range(engs[0].x_slices):
+                for e_ in engs: e_.combine_slice(k)
+        else:
+            for e_ in engs: e_.combine()
+        if engs[0].column_accumulators:
+            tot = sum(e_.y_tensor().clone() for e_ in engs)
+            for e_ in engs: e_.y_tensor().copy_(tot)
+        act = sum(e_.apply(iters, check) for e_ in engs)
+        if check:
+            if act == 0:
+                for e_ in engs: e_.finish_converged()
+                break
+        elif engs[0].iteration >= iters:
+            break
+
+
+def _loopback_gather(progs, field, n):
+    """global array over original vertex ids from the p ranks' state slots (gt_graph_vertex_ids)"""
+    out = np.zeros(n, progs[0].V[field].dtype); seen = np.zeros(n, bool)
+    for p in progs:
+        vids = p.G.vertex_ids(); keep = vids != 0xFFFFFFFF
+        out[vids[keep]] = p.V[field][keep]; assert not seen[vids[keep]].any(); seen[vids[keep]] = True
+    assert seen.all()
+    return out
+
+
 @pytest.mark.parametrize("variant", ["pb", "pb_f32msg", "edge"])
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 @pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
@@ -273,62 +325,16 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
     of the engine without RCCL. BFS labels must equal the reference's np=1 run bit for bit;
     PageRank within 1e-6 (the reference's own np>1 runs differ from np=1 by fp association too)."""
     import torch
-    from graphtap_amd import dist as gdist
     from graphtap_amd.vertex_program import _HipEngine
     monkeypatch.setenv("GRAPHTAP_SPMV", variant)   # read by gt_graph_build
     monkeypatch.setenv("GRAPHTAP_X_SLICES", str({"pb": 4, "pb_f32msg": 2, "edge": 1}[variant]))   # K slices of the exchange
     c = load_case(name); nv = c["num_vertices"]; n = nv + 1
 
-    class Loopback:
-        """dist.run's collectives replaced by copies between the p engines living in this process."""
-
     def run_all(make):
         progs = [make(r) for r in range(nranks)]
-        engs = [_HipEngine(p) for p in progs]
-        for p in progs:
-            p.initialize() if not p._already_initialized else None
-        return progs, engs
-
-    def lockstep(progs, engs, iters):
-        check = iters == 0
-        while True:
-            for e_ in engs: e_.scatter_gather()
-            if engs[0].needs_x_exchange:   # the K all-to-alls of gt_graph_exchange_plan, by device copies
-                xs = [e_.x_tensor() for e_ in engs]; sends = [e_.send_tensor() for e_ in engs]
-                plans = [e_.exchange_plan() for e_ in engs]
-                for k in range(engs[0].x_slices):
-                    for r in range(nranks):          # source
-                        so, _, sc, _ = plans[r]
-                        for d in range(nranks):      # destination
-                            _, ro, _, rc = plans[d]
-                            assert sc[k][d] == rc[k][r] and sc[k][d] % 4 == 0
-                            a = so[k] + sum(sc[k][:d]); b = ro[k] + sum(rc[k][:r])
-                            assert b + rc[k][r] <= ro[k + 1]
-                            xs[d][b:b + rc[k][r]].copy_(sends[r][a:a + sc[k][d]])
-            if engs[0].x_slices > 1 and (len(progs) + engs[0].iteration) % 2 == 0:   # exercise the sliced entry point too
-                for k in range(engs[0].x_slices):
-                    for e_ in engs: e_.combine_slice(k)
-            else:
-                for e_ in engs: e_.combine()
-            if engs[0].column_accumulators:
-                tot = sum(e_.y_tensor().clone() for e_ in engs)
-                for e_ in engs: e_.y_tensor().copy_(tot)
-            act = sum(e_.apply(iters, check) for e_ in engs)
-            if check:
-                if act == 0:
-                    for e_ in engs: e_.finish_converged()
-                    break
-            elif engs[0].iteration >= iters:
-                break
-
-    def gather(progs, field):
-        """global array over original vertex ids from the p ranks' state slots (gt_graph_vertex_ids)"""
-        out = np.zeros(n, progs[0].V[field].dtype); seen = np.zeros(n, bool)
-        for p in progs:
-            vids = p.G.vertex_ids(); keep = vids != 0xFFFFFFFF
-            out[vids[keep]] = p.V[field][keep]; assert not seen[vids[keep]].any(); seen[vids[keep]] = True
-        assert seen.all()
-        return out
+        return progs, _loopback_engines(progs)
+    lockstep = _loopback_lockstep
+    gather = lambda progs, field: _loopback_gather(progs, field, n)
 
     # BFS
     graphs = []
@@ -361,6 +367,38 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
     for p in prs + degs: p.free()
     for G in graphs: G.free()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("nranks,slices", [(4, 1), (8, 4)])
+def test_multirank_degenerate_graphs(gt, O, nranks, slices, monkeypatch):
+    """Tile-rows without entries, segments without columns, an empty edge list: the exchange plan must stay consistent
+    (all-zero blocks included) and the programs must give the oracle's answers."""
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+    nv = 40
+    cases = [np.zeros((0, 2), np.uint32),
+             np.array([[1, 2], [2, 3], [3, 1], [7, 7], [39, 0]], np.uint32),
+             np.array([[5, 6]], np.uint32)]
+    for e in cases:
+        graphs = []
+        for r in range(nranks):
+            G = gt.Graph(); G.load_edges(e, nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks)
+            graphs.append(G)
+        if len(e):
+            ref = O.run_app("cc", e, nv); want_nnz, want_label, want_it = ref["graph"].nnz, ref["label"][:nv + 1], ref["iterations"]
+        else:
+            want_nnz, want_label, want_it = 0, np.arange(nv + 1), 1
+        assert sum(G.info.nnz_local for G in graphs) == want_nnz
+        for G in graphs:   # every local column maps to a distinct global slot of a column that exists
+            t = G.tile_to_host(); i = G.info
+            l2g = t["L2G"]; used = l2g != 0xFFFFFFFF
+            assert np.unique(l2g[used]).size == used.sum() and (l2g[used] % i.seg_stride < i.seg_stride).all()
+            assert (np.diff(t["JA"].astype(np.int64))[~used] == 0).all() and t["JA"][-1] == i.nnz_local
+        progs = [gt.CC_Program(G, False, True, False, gt._ROW_) for G in graphs]
+        engs = _loopback_engines(progs)
+        _loopback_lockstep(progs, engs, 0)
+        assert (_loopback_gather(progs, "label", nv + 1) == want_label).all() and progs[0].iteration == want_it
+        for p in progs: p.free()
+        for G in graphs: G.free()
 
 
 def load_nnz(gt, c, app):
