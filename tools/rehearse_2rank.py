@@ -40,5 +40,5 @@ if rank == 0:
     assert (multi["pr"]["degree"] == single["pr"]["degree"]).all()
     rel = np.abs(multi["pr"]["rank"] - single["pr"]["rank"]) / single["pr"]["rank"]
     assert rel.max() < 1e-6 and multi["pr_disp"] == single["pr_disp"], (rel.max(), multi["pr_disp"], single["pr_disp"])
-    print("2-rank rehearsal ok: BFS/CC/SSSP bit-exact, PageRank max rel err %.2e, display %s" % (rel.max(), multi["pr_disp"][0]))
+    print("%d-rank rehearsal ok: BFS/CC/SSSP bit-exact, PageRank max rel err %.2e, display %s" % (world, rel.max(), multi["pr_disp"][0]))
 dist.barrier(); dist.destroy_process_group()
