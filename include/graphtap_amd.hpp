@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -55,13 +56,58 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
         std::ifstream fin(filepath, std::ios::binary | std::ios::ate);
         if (!fin.is_open()) throw Error("Unable to open input file");  // graph.hpp:311-314
         const uint64_t bytes = (uint64_t)fin.tellg(), rec = weighted_ ? 12 : 8;
-        if (bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
         std::vector<char> buf(bytes);
         fin.seekg(0);
         fin.read(buf.data(), (std::streamsize)bytes);
-        printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
-        load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+        // The reference tells text from binary with popen("file -b") (graph.hpp:119-145); here a file is text when its
+        // first 4 KiB are printable ASCII / white space.
+        bool text = bytes > 0;
+        for (uint64_t i = 0; i < bytes && i < 4096 && text; i++) {
+            const unsigned char c = (unsigned char)buf[i];
+            text = (c >= 32 && c < 127) || c == '\t' || c == '\n' || c == '\r';
+        }
+        if (text) {
+            std::vector<uint32_t> recs = parse_text(buf, weighted_ ? 3 : 2);
+            const uint64_t m = recs.size() / (weighted_ ? 3 : 2);
+            printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
+            load_edges(recs.data(), m, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+        } else {
+            if (bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
+            printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
+            load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+        }
         printf("Ingress time: %f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    // ASCII edge list, parread_text (graph.hpp:195-304): leading '#' / '%' / empty lines are skipped, every other line is
+    // "row col[ weight]" separated by single spaces (a different column count is "read() failure", :250-257), the list
+    // ends at the first empty line. Comment lines further down are skipped too (the reference would reject them).
+    static std::vector<uint32_t> parse_text(const std::vector<char> &buf, int columns) {
+        std::vector<uint32_t> out;
+        const char *p = buf.data(), *end = p + buf.size();
+        bool started = false;
+        while (p < end) {
+            const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = eol ? eol : end;
+            const char *stop = (le > p && le[-1] == '\r') ? le - 1 : le;
+            if (stop == p) { if (started) break; }
+            else if (*p == '#' || *p == '%') { /* comment */ }
+            else {
+                started = true;
+                int spaces = 0;
+                for (const char *q = p; q < stop; q++) spaces += (*q == ' ');
+                if (spaces + 1 != columns) throw Error("read() failure \"" + std::string(p, stop) + "\"");
+                const char *q = p;
+                for (int c = 0; c < columns; c++) {
+                    uint64_t v = 0; bool digit = false;
+                    while (q < stop && *q >= '0' && *q <= '9') { v = v * 10 + (uint64_t)(*q - '0'); q++; digit = true; }
+                    if (!digit || v > 0xFFFFFFFFull || (q < stop && *q != ' ')) throw Error("read() failure \"" + std::string(p, stop) + "\"");
+                    out.push_back((uint32_t)v);
+                    q++;
+                }
+            }
+            p = eol ? eol + 1 : end;
+        }
+        return out;
     }
     void load_edges(const void *edges, uint64_t m, uint32_t num_vertices, bool directed, bool transpose, bool self_loops,
                     bool acyclic, bool parallel_edges, Compression_type compression_type, bool on_device = false) {

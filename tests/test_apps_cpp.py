@@ -80,3 +80,67 @@ def test_deg_checksum1_and_timing_record():
     assert "Mode & skew : 0 & 0.196679" in r.stdout
     assert "Max index : 613" in r.stdout and "Max value : 1983" in r.stdout
     assert "TIMING scatter_gather" in r.stdout
+
+
+# ------------------------------------------------------------------------------- edge-list converter (host only)
+CONVERTER_CASES = {  # as in tests/golden/make_converter_golden.py
+    "txt_to_bin": ("converter_in.txt", 0, 0, 1, 0, None),
+    "txt_to_wbin": ("converter_in.txt", 0, 0, 1, 1, None),
+    "wtxt_to_wbin_off3": ("converter_in_w.txt", 0, 1, 1, 1, 3),
+    "wtxt_to_txt": ("converter_in_w.txt", 0, 1, 0, 0, None),
+    "bin_to_wtxt": ("converter_txt_to_bin.out", 1, 0, 0, 1, None),
+    "wbin_to_bin": ("converter_txt_to_wbin.out", 1, 1, 1, 0, 1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CONVERTER_CASES))
+def test_converter_matches_the_reference_converter(case, tmp_path):
+    """apps/converter.cpp against the files and statistics lines the unmodified reference converter produced
+    (tests/golden/converter_*; weights of unweighted inputs come from the C library's default-seeded rand())."""
+    inp, ib, iw, ob, ow, off = CONVERTER_CASES[case]
+    out = tmp_path / "out"
+    args = [inp, ib, iw, out, ob, ow] + ([off] if off is not None else [])
+    exe = os.path.join(BIN, "converter")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apps"), "bin/converter"])
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=60, cwd=GOLDEN)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "converter_%s.out" % case), "rb").read()
+    assert r.stdout == open(os.path.join(GOLDEN, "converter_%s.stdout" % case)).read()
+    ref = os.path.join(ROOT, "oracle", "_ref", "converter")
+    if os.path.exists(ref):   # live comparison where the reference build is present
+        out2 = tmp_path / "out_ref"
+        args[3] = out2
+        r2 = subprocess.run([ref, *map(str, args)], capture_output=True, text=True, timeout=60, cwd=GOLDEN)
+        assert r2.returncode == 0 and out2.read_bytes() == out.read_bytes() and r2.stdout == r.stdout
+
+
+def test_converter_errors():
+    exe = os.path.join(BIN, "converter")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apps"), "bin/converter"])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.startswith("Usage: ")
+    r = subprocess.run([exe, "/nonexistent", "0", "0", "/tmp/x", "1", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unable to open input file" in r.stderr
+    r = subprocess.run([exe, os.path.join(GOLDEN, "converter_in.txt"), "0", "1", "/dev/null", "1", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "read() failure" in r.stderr     # two columns where three were announced
+
+
+@pytest.mark.gpu
+def test_mains_read_text_edge_lists(tmp_path):
+    """ASCII edge lists (graph.hpp:195-304) through the C++ shim: the same printed results as for the binary file."""
+    conv = os.path.join(BIN, "converter")
+    txt, wtxt = tmp_path / "rmat10.txt", tmp_path / "rmat10_w.txt"
+    subprocess.check_call([conv, os.path.join(GOLDEN, "rmat10_1024.bin"), "1", "0", str(txt), "0", "0"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([conv, os.path.join(GOLDEN, "rmat10_1024_w.bin"), "1", "1", str(wtxt), "0", "1"], stdout=subprocess.DEVNULL)
+    txt.write_text("# R-MAT scale 10\n% edge factor 16\n" + txt.read_text())
+    keep = lambda s: [l for l in s.splitlines() if l.startswith(("Iterations", "Value checksum", "Reachable", "vertex["))]
+    for app, f_bin, f_txt, arg in (("cc", "rmat10_1024.bin", txt, None), ("sssp", "rmat10_1024_w.bin", wtxt, 0)):
+        extra = [] if arg is None else [arg]
+        a = run(app, os.path.join(GOLDEN, f_bin), 1024, *extra); b = run(app, f_txt, 1024, *extra)
+        assert a.returncode == 0 and b.returncode == 0, b.stderr
+        assert keep(a.stdout) == keep(b.stdout) and len(keep(a.stdout)) == 34
+        assert "Read %d edges" % (16384) in b.stdout
+    r = run("cc", wtxt, 1024)      # three columns where cc expects two
+    assert r.returncode == 1 and "read() failure" in r.stderr
