@@ -12,10 +12,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=24)
 ap.add_argument("--apps", default="bfs,cc,sssp")
 ap.add_argument("--root", type=int, default=None)
+ap.add_argument("--edge-factor", type=int, default=16)
 args = ap.parse_args()
 L = _lib.lib(); _lib.require_gpu(); _lib.check(L.gt_set_device(0))
 scale, nv = args.scale, 1 << args.scale
-m = 16 << scale
+m = args.edge_factor << scale
 for app in args.apps.split(","):
     weighted = app == "sssp"
     d = C.c_void_p(); _lib.check(L.gt_malloc(C.byref(d), m * (12 if weighted else 8)))
@@ -40,7 +41,7 @@ for app in args.apps.split(","):
     P.execute(1 if app == "deg" else 0)
     st = P.stats
     cs = P.checksum(out=None)
-    print(json.dumps({"app": app, "scale": scale, "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
+    print(json.dumps({"app": app, "scale": scale, "edge_factor": args.edge_factor, "root": int(P.root), "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
                       "iterations": st.iterations, "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
                       "spmv_ms_mean": st.spmv_ms / max(st.spmv_launches, 1), "ingress_s": round(ingress, 3),
                       "value_checksum": cs[0], "reachable": cs[1]}), flush=True)
