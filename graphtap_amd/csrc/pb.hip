@@ -32,9 +32,10 @@
 //                 (8192 = pad), bit 14: last entry of its (quad, row) group, bit 15: first entry of a run
 //   LROW[k]  u16  k-order = outputs, runs sorted by (bin, chunk); row & (R-1)
 //   WT[v]    u32  weights in v-order (min-plus only)
-//   G[g]     32 B per 256 entries of the v-order: the k-slot of lane 0's first output and of the first six
-//                 run heads of the group, so that no load of phase 1 depends on another load
-//   KSTART[s]     k-slot where run s starts (groups with seven or more run heads only)
+//   G[g]     32 B per 256 entries of the v-order: the k-slot of lane 0's first output and, for the first six
+//                 run heads of the group, (k-slot of the run - outputs of the group before the head), so that no
+//                 load of phase 1 depends on another load and a lane gets its slots with one ds_bpermute
+//   KSTART[s]     k-slot where run s starts - outputs of the whole v-order before it (groups with 7+ run heads)
 // HBM traffic per entry per SpMV: 2 + 0.125 (phase 1 in) + (F + F + 2) / D (value stream out and back, LROW),
 // D = entries per output, F = bytes of a message in flight.
 #include <hipcub/hipcub.hpp>
@@ -237,13 +238,21 @@ __global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32
         uint32_t lo = 0, hi = nrun;
         while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (pvstart[mid] <= pv) lo = mid + 1; else hi = mid; }
         const uint32_t s0 = lo - 1;
+        // k-slot of an output = its position among the group's outputs + a per-run constant ("delta"): the group's
+        // first run continues at k0; a run that starts inside the group at k-slot pkstart has delta = pkstart - (outputs
+        // of the group before its head) = pkstart - X[pvstart] + X[pv]
         GroupRec r;
         r.s = s0; r.k0 = pkstart[s0] + (X[pv] - X[pvstart[s0]]);
-        for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nrun) ? pkstart[s0 + 1 + i] : 0;
+        for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nrun) ? pkstart[s0 + 1 + i] - X[pvstart[s0 + 1 + i]] + X[pv] : 0;
         G[g] = r;
     }
 }
 
+// KSTART[s] = pkstart[s] - X[pvstart[s]]: the delta of run s is KSTART[s] + X[group start] (groups with 7+ run heads)
+__global__ void k_kstart(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ X,
+                         uint32_t nrun, uint32_t *__restrict__ KSTART) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrun; r += gridDim.x * blockDim.x) KSTART[r] = pkstart[r] - X[pvstart[r]];
+}
 // chunk range of every phase-2 work item: runs are sorted by (bin, chunk) in the k-order, kscan = their k-starts
 __global__ void k_work_chunks(BinWork *__restrict__ work, uint32_t nwork, const uint32_t *__restrict__ kscan, const uint32_t *__restrict__ order,
                               const uint32_t *__restrict__ runkey, uint32_t nrun, int binbits) {
@@ -340,7 +349,6 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);   // lanes 0..lane
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 4;   // 256-entry groups in flight per wave
     const uint32_t gend = q1c >> 6;   // chunk ranges are multiples of 256 entries = 64 quads (k_align_chunks)
@@ -371,30 +379,28 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // exclusive prefix of the output count over the wave without touching the LDS pipe: one ballot + mbcnt per bit
             auto below = [](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
             const uint32_t pex = below(__ballot(e0)) + below(__ballot(e1)) + below(__ballot(e2)) + below(__ballot(e3));
-            // k-slot of this lane's outputs: its run is the group's first run (k-slot k0 = dword 0 of the group record) or
-            // starts at the nh-th run head of the group (dword nh, nh = 1..6; KSTART beyond). A quad never straddles runs.
+            // k-slot of an output = its position in the wave's row + delta, delta a constant of the lane's run: dword 0 of
+            // the group record for the group's first run, dword nh for the run that starts at the nh-th run head of the
+            // group (nh = 1..6; the build folds "outputs of the group before that head" into it). A quad never straddles runs.
             const bool head = lane != 0 && (lc[u].c[0] & HEAD) != 0;
             const uint64_t Hb = __ballot(head);
             const uint32_t nh = below(Hb) + (head ? 1u : 0u);                       // run heads at or before this lane
-            const uint64_t hm = Hb & lane_le;
-            const int hl = hm ? 63 - __clzll((unsigned long long)hm) : 0;            // lane of my run's head
-            uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nh < 7 ? nh : 0u) << 2), (int)gw[u]);
+            uint32_t delta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nh < 7 ? nh : 0u) << 2), (int)gw[u]);
             if (__popcll((unsigned long long)Hb) >= 7) {
                 // rare: seven or more run heads in one 256-entry group. Walks the heads beyond the sixth with wave-uniform
                 // (scalar) loads: a vector load here would put a vmcnt(0) wait -- prefetches and stores included -- into
-                // every group of the common path
+                // every group of the common path. delta(run s) = KSTART[s] + X[group start], X[group start] = k0 - KSTART[s0].
                 const uint32_t s0 = __builtin_amdgcn_readlane(gw[u], 7);
+                const uint32_t xg = __builtin_amdgcn_readlane(gw[u], 0) - KSTART[s0];
                 uint64_t Hm = Hb;
                 for (int i = 0; i < 6; i++) Hm &= Hm - 1;
                 for (uint32_t i = 7; Hm; i++) {
                     const uint32_t hlane = (uint32_t)__ffsll((unsigned long long)Hm) - 1;
                     Hm &= Hm - 1;
-                    const uint32_t ks = KSTART[s0 + i];
-                    if (lane >= hlane) base = ks;
+                    const uint32_t ks = KSTART[s0 + i] + xg;
+                    if (lane >= hlane) delta = ks;
                 }
             }
-            const uint32_t off = nh ? (uint32_t)__builtin_amdgcn_ds_bpermute(hl << 2, (int)pex) : 0u;
-            const uint32_t delta = base - off;                                       // k-slot = position in the wave's row + delta
             // segmented combine over the quad: one output per (quad, row) group, compacted together with its k-slot into
             // the wave's LDS row at [pex, p) so that the stores below are coalesced runs; entries that do not end a group
             // write to a per-lane dump slot instead of branching
@@ -686,7 +692,7 @@ int gt_pb_build(gt_graph *g) {
                                                    pb->LCOL, pb->LROW, pb->WT);
     k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
     PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nrun + 64) * 4, s));
-    PB_HIP(hipMemcpyAsync(pb->KSTART, pkstart.p, (uint64_t)nrun * 4, hipMemcpyDeviceToDevice, s));
+    k_kstart<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, pb->KSTART);
     // phase-2 work list (host: nbins is small)
     std::vector<uint32_t> hoff(pb->nbins + 1);
     PB_HIP(hipMemcpyAsync(hoff.data(), binoff.p, (uint64_t)(pb->nbins + 1) * 4, hipMemcpyDeviceToHost, s));
