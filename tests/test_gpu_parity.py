@@ -401,6 +401,50 @@ def test_multirank_degenerate_graphs(gt, O, nranks, slices, monkeypatch):
         for G in graphs: G.free()
 
 
+def test_multirank_midsize_pagerank_and_bfs_equal_single_rank(gt, monkeypatch):
+    """R-MAT 18 over 8 tile-rows (several phase-1 windows per exchange slice, split row bins) against the same graph
+    on one rank: PageRank (f32 messages) to 1e-6, BFS bit for bit."""
+    from graphtap_amd.rmat import rmat_edges
+    monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", "4")
+    scale, p = 18, 8
+    nv = 1 << scale; n = nv + 1
+    e = rmat_edges(scale, 16, 5)
+
+    def pagerank(nranks):
+        graphs = [gt.Graph() for _ in range(nranks)]
+        for r, G in enumerate(graphs):
+            G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=r, nranks=nranks)
+        degs = [gt.Deg_Program(G, True, False, False, gt._COL_) for G in graphs]
+        _loopback_lockstep(degs, _loopback_engines(degs), 1)
+        prs = []
+        for G, D in zip(graphs, degs):
+            P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(D); prs.append(P)
+        _loopback_lockstep(prs, _loopback_engines(prs), 10)
+        out = _loopback_gather(prs, "rank", n), _loopback_gather(prs, "degree", n)
+        for P in prs + degs: P.free()
+        for G in graphs: G.free()
+        return out
+
+    def bfs(nranks):
+        graphs = [gt.Graph() for _ in range(nranks)]
+        for r, G in enumerate(graphs):
+            G.load_edges(e, nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks)
+        progs = []
+        for G in graphs:
+            P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = 3; progs.append(P)
+        _loopback_lockstep(progs, _loopback_engines(progs), 0)
+        out = _loopback_gather(progs, "parent", n), _loopback_gather(progs, "hops", n), progs[0].iteration
+        for P in progs: P.free()
+        for G in graphs: G.free()
+        return out
+
+    r1, d1 = pagerank(1); r8, d8 = pagerank(p)
+    assert (d1 == d8).all() and (np.abs(r8 - r1) / r1).max() < PR_RTOL
+    a, b = bfs(1), bfs(p)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[2] == b[2]
+
+
 def load_nnz(gt, c, app):
     from oracle import oracle as O
     return O.OracleGraph(c["edges"], c["num_vertices"], **O.APP_FLAGS[app]).nnz
