@@ -217,8 +217,8 @@ def main():
     if os.path.exists(tp):
         try:
             rec = json.load(open(tp))
-            key = "scale%d_gpus%d" % (scale, world)
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            key = "scale%d_gpus%d" % (scale, world)   # collected for the default variant (pb_f32msg) only
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch") if args.spmv == "pb_f32msg" else None
         except Exception:
             traffic = None
     out = {
