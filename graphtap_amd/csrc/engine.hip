@@ -68,6 +68,10 @@ struct gt_program {
     uint32_t spmv_done = 0;     // complete SpMVs among the timed event pairs (a sliced SpMV records one pair per slice)
     uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
     bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
+    // sliced combine (several ranks): phase 1 of slice k runs on helper stream k % size so that the tail of one slice
+    // overlaps the start of the next (and, in the pipelined driver, the exchange of the later slices)
+    std::vector<hipStream_t> slice_streams;
+    std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
 };
 
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
@@ -395,6 +399,9 @@ int gt_program_free(gt_program *p) {
     void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->slice_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->slice_done) (void)hipEventDestroy(e);
+    for (hipStream_t st : p->slice_streams) (void)hipStreamDestroy(st);
     delete p;
     return GT_OK;
 }
@@ -610,19 +617,58 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         if (p->stationary && !p->y_clean) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
         p->y_clean = false;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) {
-        if (p->ev_used + 2 > p->ev.size()) {
-            hipEvent_t a, b;
-            GT_HIP(hipEventCreate(&a)); GT_HIP(hipEventCreate(&b));
-            p->ev.push_back(a); p->ev.push_back(b);
+    auto timing_event = [&](hipEvent_t *out) -> int {
+        if (p->ev_used + 1 > p->ev.size()) { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
+        *out = p->ev[p->ev_used++];
+        return GT_OK;
+    };
+    const bool sliced = K > 1 && !(lo == 0 && hi >= K);
+    if (!sliced) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (timed) {
+            int st = timing_event(&e0); if (st != GT_OK) return st;
+            st = timing_event(&e1); if (st != GT_OK) return st;
+            GT_HIP(hipEventRecord(e0, s));
         }
-        e0 = p->ev[p->ev_used]; e1 = p->ev[p->ev_used + 1]; p->ev_used += 2;
-        GT_HIP(hipEventRecord(e0, s));
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi);
+        if (st != GT_OK) return st;
+        if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
+        return GT_OK;
     }
-    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi);
-    if (st != GT_OK) return st;
-    if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
+    // Slice by slice (the pipelined multi-GPU loop): launched back to back on ONE stream the K phase-1 kernels of a
+    // tile-row of 8 of R-MAT-26 cost +0.03-0.05 ms at K = 2 and +0.08 ms at K = 4 over one launch (0.37 ms per step):
+    // a slice's ~650 workgroups fill the 512 resident slots 1.3 times and every launch drains before the next starts.
+    // So each slice goes to a helper stream that waits only for what the caller had enqueued on `stream` when the slice
+    // was issued (its exchange), and phase 2 joins them: +0.015 ms at K = 2, +0.06 ms at K = 4 (rocprofv3 timeline). Timing: one event pair per SpMV, first slice issued ->
+    // phase 2 finished (exchange waits that were not hidden are inside).
+    if (p->slice_streams.empty()) {
+        const uint32_t ns = K < 3 ? K : 3;   // HIP maps streams onto 4 hardware queues: `stream` + 3 helpers run truly side by side
+        for (uint32_t i = 0; i < ns; i++) { hipStream_t t; GT_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); p->slice_streams.push_back(t); }
+        for (uint32_t i = 0; i < K; i++) {
+            hipEvent_t a, b;
+            GT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); GT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            p->slice_in.push_back(a); p->slice_done.push_back(b);
+        }
+    }
+    if (lo == 0) {
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, 0, 0, GT_PB_PREPARE);
+        if (st != GT_OK) return st;
+        if (timed) { hipEvent_t e0; st = timing_event(&e0); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e0, s)); }
+    }
+    for (uint32_t k = lo; k < hi && k < K; k++) {
+        hipStream_t hs = p->slice_streams[k % p->slice_streams.size()];
+        GT_HIP(hipEventRecord(p->slice_in[k], s));
+        GT_HIP(hipStreamWaitEvent(hs, p->slice_in[k], 0));
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, hs, p->x_f32, p, p->init_epoch, k, k + 1, GT_PB_PHASE1);
+        if (st != GT_OK) return st;
+        GT_HIP(hipEventRecord(p->slice_done[k], hs));
+    }
+    if (hi >= K) {
+        for (uint32_t k = 0; k < K; k++) GT_HIP(hipStreamWaitEvent(s, p->slice_done[k], 0));
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2);
+        if (st != GT_OK) return st;
+        if (timed) { hipEvent_t e1; st = timing_event(&e1); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e1, s)); p->spmv_done++; }
+    }
     return GT_OK;
 }
 int gt_program_combine(gt_program *p) {

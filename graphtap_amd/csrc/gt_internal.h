@@ -65,9 +65,12 @@ struct gt_graph {
 // pb.hip
 int gt_pb_build(gt_graph *g);
 void gt_pb_free(struct gt_pb *pb);
-// slices [slice_lo, slice_hi) of phase 1; phase 2 runs when slice_hi == x_slices
+// slices [slice_lo, slice_hi) of phase 1; phase 2 runs when slice_hi == x_slices. `phases` = 0 does what the slice range
+// implies (prepare with slice 0, phase 1, phase 2 with the last slice); the engine's sliced path passes the stages
+// one by one so that the phase-1 launches of different slices can run on different streams.
+enum { GT_PB_PREPARE = 1u, GT_PB_PHASE1 = 2u, GT_PB_PHASE2 = 4u };
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi);
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
@@ -88,4 +91,5 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
-                   const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu);
+                   const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu,
+                   unsigned phases = 0);

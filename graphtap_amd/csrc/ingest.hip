@@ -294,7 +294,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     uint32_t K = 1;
     if (p > 1) {
         const char *e = getenv("GRAPHTAP_X_SLICES");
-        K = e ? (uint32_t)atoi(e) : 4u;
+        K = e ? (uint32_t)atoi(e) : 2u;   // slicing is not free (engine.hip, combine_impl): two slices hide half of the exchange
         if (K < 1) K = 1;
         if (K > 64) K = 64;
     }

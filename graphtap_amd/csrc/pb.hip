@@ -747,11 +747,10 @@ int gt_pb_build(gt_graph *g) {
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
-                  uint32_t slice_lo, uint32_t slice_hi) {
-    const uint32_t K = g->info.x_slices;
+                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see k_pb_scatter).
     const bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
-    if (slice_lo == 0) {
+    if (phases & GT_PB_PREPARE) {
         if (filter && (pb->val_owner != owner || pb->val_epoch != epoch)) { pb->val_min = -1; pb->val_owner = owner; pb->val_epoch = epoch; }
         if (!filter) pb->val_owner = nullptr;
         if (pb->val_min != (IS_MIN ? 1 : 0)) {   // pad slots (and, with filtering, every slot) start at the semiring's neutral value
@@ -759,12 +758,14 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             pb->val_min = IS_MIN ? 1 : 0;
         }
     }
-    const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
-    if (c1 > c0)
-        k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
-            pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
-            (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, pb->launch_order, c0);
-    if (slice_hi >= K) {
+    if (phases & GT_PB_PHASE1) {
+        const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
+        if (c1 > c0)
+            k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
+                pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
+                (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, pb->launch_order, c0);
+    }
+    if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
         k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
                                                                     filter ? pb->active_prefix : nullptr);
@@ -774,14 +775,17 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
 }
 
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi) {
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
+    const uint32_t K = g->info.x_slices;
+    if (slice_hi > K) slice_hi = K;
+    if (phases == 0) phases = (slice_lo == 0 ? GT_PB_PREPARE : 0u) | GT_PB_PHASE1 | (slice_hi >= K ? GT_PB_PHASE2 : 0u);
     // one value stream per graph (SpMVs of one graph must not overlap in time); its element type follows the SpMV
     const uint32_t need = (semiring == GT_PLUS_F64 && !f32_messages) ? 8 : 4;
     const int kind = (semiring == GT_PLUS_F64) ? (f32_messages ? 1 : 2) : 3;
-    if (pb->val_bytes != need || pb->val_kind != kind) {
+    if ((phases & GT_PB_PREPARE) && (pb->val_bytes != need || pb->val_kind != kind)) {
         if (pb->val_bytes < need) {
             if (pb->VAL) GT_HIP(hipFree(pb->VAL));
             pb->VAL = nullptr; pb->val_bytes = 0;
@@ -792,14 +796,14 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

@@ -13,6 +13,7 @@ from graphtap_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=26); ap.add_argument("--nranks", type=int, default=8)
 ap.add_argument("--rank", type=int, default=0); ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--sliced", action="store_true", help="drive the SpMV slice by slice (gt_program_combine_slice), as the pipelined multi-GPU loop does")
 a = ap.parse_args()
 L = _lib.lib(); _lib.require_gpu(); _lib.check(L.gt_set_device(0))
 nv, m = 1 << a.scale, 16 << a.scale
@@ -24,8 +25,14 @@ h = V._handle(); _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_pro
 VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V)   # partial degrees: timing only
 h = VR._handle()
 _lib.check(L.gt_program_enable_timing(h, 1))
+K = G.info.x_slices
 def step():
-    _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 0x7fffffff, None))
+    _lib.check(L.gt_program_scatter_gather(h))
+    if a.sliced:
+        for k in range(K): _lib.check(L.gt_program_combine_slice(h, k))
+    else:
+        _lib.check(L.gt_program_combine(h))
+    _lib.check(L.gt_program_apply(h, 0x7fffffff, None))
 for _ in range(3): step()
 ms, n = C.c_double(), C.c_uint32(); _lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
 _lib.check(L.gt_device_synchronize()); t0 = time.perf_counter()
@@ -33,7 +40,7 @@ for _ in range(a.steps): step()
 _lib.check(L.gt_device_synchronize()); dt = time.perf_counter() - t0
 _lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
 i = G.info
-print(json.dumps({"scale": a.scale, "rank": a.rank, "nranks": a.nranks, "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
+print(json.dumps({"scale": a.scale, "rank": a.rank, "nranks": a.nranks, "x_slices": int(K), "sliced": bool(a.sliced), "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
                   "seg_stride": int(i.seg_stride), "ms_per_step_compute_only": dt * 1e3 / a.steps, "spmv_ms": ms.value / max(n.value, 1),
                   "ncols_local": int(i.ncols_local), "recv_bytes_f32": int(sum(map(sum, G.exchange_plan()[3])) * 4),
                   "send_bytes_f32": int(i.send_elems * 4), "allgather_bytes_f32": int(i.nnzcols_global * 4)}))
