@@ -420,7 +420,12 @@ def test_multirank_midsize_pagerank_and_bfs_equal_single_rank(gt, monkeypatch):
         prs = []
         for G, D in zip(graphs, degs):
             P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(D); prs.append(P)
+        L = gt._lib.lib()
+        gt._lib.check(L.gt_program_enable_timing(prs[-1]._handle(), 1))
         _loopback_lockstep(prs, _loopback_engines(prs), 10)
+        ms, launches = C.c_double(), C.c_uint32()
+        gt._lib.check(L.gt_program_timing(prs[-1]._handle(), C.byref(ms), C.byref(launches), 1))
+        assert launches.value == 10 and ms.value > 0      # one timed SpMV per iteration, sliced or not
         out = _loopback_gather(prs, "rank", n), _loopback_gather(prs, "degree", n)
         for P in prs + degs: P.free()
         for G in graphs: G.free()
