@@ -639,7 +639,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
     // tile-row of 8 of R-MAT-26 cost +0.03-0.05 ms at K = 2 and +0.08 ms at K = 4 over one launch (0.37 ms per step):
     // a slice's ~650 workgroups fill the 512 resident slots 1.3 times and every launch drains before the next starts.
     // So each slice goes to a helper stream that waits only for what the caller had enqueued on `stream` when the slice
-    // was issued (its exchange), and phase 2 joins them: +0.015 ms at K = 2, +0.06 ms at K = 4 (rocprofv3 timeline). Timing: one event pair per SpMV, first slice issued ->
+    // was issued (its exchange), and phase 2 joins them: +0.025 ms at K = 2, +0.05 ms at K = 4 (tools/bench_tilerow.py --sliced, rocprofv3 timeline). Timing: one event pair per SpMV, first slice issued ->
     // phase 2 finished (exchange waits that were not hidden are inside).
     if (p->slice_streams.empty()) {
         const uint32_t ns = K < 3 ? K : 3;   // HIP maps streams onto 4 hardware queues: `stream` + 3 helpers run truly side by side
