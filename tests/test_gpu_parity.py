@@ -369,7 +369,7 @@ def test_tile_rows_of_p_ranks_reproduce_the_single_rank_run(gt, name, nranks, va
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("nranks,slices", [(4, 1), (8, 4)])
+@pytest.mark.parametrize("nranks,slices", [(4, 1), (8, 4), (3, 64)])
 def test_multirank_degenerate_graphs(gt, O, nranks, slices, monkeypatch):
     """Tile-rows without entries, segments without columns, an empty edge list: the exchange plan must stay consistent
     (all-zero blocks included) and the programs must give the oracle's answers."""
