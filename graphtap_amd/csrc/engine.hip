@@ -70,6 +70,10 @@ struct gt_program {
     bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
     // sliced combine (several ranks): phase 1 of slice k runs on helper stream k % size so that the tail of one slice
     // overlaps the start of the next (and, in the pipelined driver, the exchange of the later slices)
+    // gt_program_execute: PageRank's apply of this iteration is fused into phase 2 for the row bins one workgroup owns
+    bool fuse_armed = false, fused = false;   // armed before combine; fused = the combine of this iteration did it
+    uint32_t fuse_iters = 0;
+    bool fuse_count = false;
     std::vector<hipStream_t> slice_streams;
     std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
 };
@@ -155,9 +159,10 @@ template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
                                TX *__restrict__ x, double alpha, double tol, int cf, int last,
-                               unsigned long long *d_active) {
+                               unsigned long long *d_active, const uint8_t *__restrict__ bin_done) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
+        if (bin_done && bin_done[r >> GT_PB_ROW_BIN_BITS]) continue;   // applied by the fused flush of phase 2 (pb.hip)
         const uint32_t c = R2C[r];
         const bool source = (c == 0xFFFFFFFFu);
         const double yr = y[r];
@@ -630,8 +635,17 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
             st = timing_event(&e1); if (st != GT_OK) return st;
             GT_HIP(hipEventRecord(e0, s));
         }
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi);
+        gt_pr_epilogue epi{};
+        const bool fuse = p->fuse_armed && p->prm.kind == GT_PR && g->spmv_variant != GT_SPMV_EDGE && g->pb != nullptr;
+        if (fuse) {
+            const bool cf = (p->prm.compression == GT_TCSC_CF);
+            epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, g->R2C, p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
+                                 cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr};
+            if (p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
+        }
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr);
         if (st != GT_OK) return st;
+        p->fused = fuse;
         if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
         return GT_OK;
     }
@@ -706,7 +720,11 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     const uint32_t nr = g->info.nnzrows, H = g->info.tile_height;
     if (p->converged) { if (active) *active = 0; return GT_OK; }
     unsigned long long *d_active = active ? p->d_active : nullptr;   // counted only when the caller wants it (converge mode)
-    if (d_active) GT_HIP(hipMemsetAsync(d_active, 0, sizeof(unsigned long long), s));
+    const bool fused = p->fused;   // phase 2 already applied the rows of its single-workgroup bins (and counted them)
+    p->fused = false; p->fuse_armed = false;
+    GT_REQUIRE(!fused || ((active != nullptr) == p->fuse_count && num_iterations == p->fuse_iters), GT_ERR_STATE,
+               "apply() after a fused combine must use the arguments the fusion was armed with");
+    if (d_active && !fused) GT_HIP(hipMemsetAsync(d_active, 0, sizeof(unsigned long long), s));
     const bool cf = (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF);
     if (p->iteration == 0 && !cf) k_clear_empty_rows<<<grid_for(H), TPB, 0, s>>>(p->C, g->IJ, H);
     switch (p->prm.kind) {
@@ -722,10 +740,10 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             void *xm = p->xseg ? p->xseg : p->x;   // next iteration's messages of the owned columns
             if (nr && p->x_f32)
                 k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
-                                                                   p->prm.alpha, p->prm.tol, cf, last, d_active);
+                                                                   p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
             else if (nr)
                 k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
-                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active);
+                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
         }
@@ -771,6 +789,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
     // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
     const bool phase_timing = stats != nullptr && getenv("GRAPHTAP_TIMING") != nullptr;
+    const bool fuse_apply = !(getenv("GRAPHTAP_FUSE_APPLY") != nullptr && atoi(getenv("GRAPHTAP_FUSE_APPLY")) == 0);   // on by default
     double t_sg = 0, t_cb = 0, t_ap = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc) -> int {
@@ -782,6 +801,8 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         auto tp = now();
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
         st = lap(tp, t_sg); if (st != GT_OK) return st;
+        // PageRank: apply follows combine at once, so phase 2 may apply the rows whose sums it completes (pb.hip)
+        p->fuse_armed = fuse_apply && p->prm.kind == GT_PR && !p->converged; p->fuse_iters = iters; p->fuse_count = check;
         st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
         st = lap(tp, t_cb); if (st != GT_OK) return st;
         uint64_t active = 0;

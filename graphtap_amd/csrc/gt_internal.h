@@ -60,6 +60,7 @@ struct gt_graph {
     int spmv_variant = 1;        // gt_spmv_variant
 };
 
+#define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
 #define GT_PB_WINDOW 8192u   // columns per phase-1 window (pb.hip); slice widths are multiples of it
 
 // pb.hip
@@ -69,8 +70,20 @@ void gt_pb_free(struct gt_pb *pb);
 // implies (prepare with slice 0, phase 1, phase 2 with the last slice); the engine's sliced path passes the stages
 // one by one so that the phase-1 launches of different slices can run on different streams.
 enum { GT_PB_PREPARE = 1u, GT_PB_PHASE1 = 2u, GT_PB_PHASE2 = 4u };
+// PageRank's applicator of iteration t + messenger of iteration t+1 (pr.h:31-33, 43-47) fused into phase 2: a row bin
+// that ONE phase-2 workgroup owns has its complete sums in LDS at flush time, so that workgroup applies its rows
+// directly and y is never touched for them; the rows of split bins go through y and k_pr_apply_msg as before
+// (gt_pb_bin_single tells the two apart).
+struct gt_pr_epilogue {
+    double *rank_c; const uint32_t *deg_c; uint8_t *C_c; const uint32_t *R2C;
+    void *x; int x_f32;
+    double alpha, tol; int cf, last;
+    unsigned long long *d_active;
+};
+const uint8_t *gt_pb_bin_single(const gt_graph *g);   // [row bins] 1 = one phase-2 workgroup owns the bin
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0);
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
+               const gt_pr_epilogue *epi = nullptr);
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
@@ -92,4 +105,4 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
                    const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu,
-                   unsigned phases = 0);
+                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr);

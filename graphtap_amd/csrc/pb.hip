@@ -44,13 +44,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 #include <vector>
 
 #include "gt_internal.h"
 
 namespace {
 
-constexpr int RB = 14;                 // log2 rows per bin
+constexpr int RB = GT_PB_ROW_BIN_BITS;  // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS
 constexpr uint32_t W = GT_PB_WINDOW;   // 8192 columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
 // Entries per chunk: large chunks make long runs (mean run ~300 entries at 2^20 on R-MAT-26), but the grid
@@ -62,7 +63,8 @@ static uint32_t ch_default(uint32_t nnz) {
     while (ch < (1u << 20) && (uint64_t)ch * 2048 <= nnz) ch <<= 1;
     return ch;
 }
-constexpr uint32_t EPW = 1u << 18;     // (padded) entries per phase-2 workgroup
+constexpr uint32_t EPW = 1u << 19;     // value-stream slots per phase-2 workgroup: a bin below it keeps ONE workgroup, whose flush
+                                       // can then apply PageRank's rows directly (2^18 and 2^19 stream equally fast, 2^20 is 2-10 % slower)
 constexpr int P1_THREADS = 1024;
 constexpr int P2_THREADS = 1024;
 #ifndef GT_P2_U
@@ -438,10 +440,11 @@ template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *a
     else atomicAdd(&acc[r], a);
 }
 
-template <class T, class TV, bool IS_MIN>
+// FUSE: 0 = plain SpMV; 1 / 2 = PageRank epilogue (gt_pr_epilogue) with an f32 / f64 message vector
+template <class T, class TV, bool IS_MIN, int FUSE>
 __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restrict__ work, const C4 *__restrict__ LROW4,
                                                           const V4<TV> *__restrict__ VAL4, uint32_t nrows, T *__restrict__ y,
-                                                          const uint32_t *__restrict__ active_prefix) {
+                                                          const uint32_t *__restrict__ active_prefix, gt_pr_epilogue epi) {
     __shared__ T acc[R];
     const BinWork wk = work[blockIdx.x];
     if (active_prefix && active_prefix[wk.c_hi + 1] == active_prefix[wk.c_lo]) return;   // no active chunk feeds this slice
@@ -470,6 +473,37 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     __syncthreads();
     const uint32_t row0 = wk.bin << RB;
     const uint32_t rn = (nrows - row0 < R) ? nrows - row0 : R;
+    if constexpr (FUSE != 0) {
+        if (wk.single) {   // complete sums of the bin's rows: apply them here (same arithmetic as k_pr_apply_msg, engine.hip)
+            using TX = typename std::conditional<FUSE == 1, float, double>::type;
+            TX *__restrict__ xo = (TX *)epi.x;
+            unsigned act = 0;
+            for (uint32_t i = threadIdx.x; i < rn; i += P2_THREADS) {
+                const uint32_t r = row0 + i, c = epi.R2C[r];
+                const bool source = (c == 0xFFFFFFFFu);
+                if (epi.cf && source && !epi.last) continue;   // vp:1671-1691
+                const double tmp = epi.rank_c[r];
+                const double nv = epi.alpha + (1.0 - epi.alpha) * (double)acc[i];
+                epi.rank_c[r] = nv;
+                const uint8_t ch = fabs(nv - tmp) > epi.tol;
+                epi.C_c[r] = ch;
+                act += (ch && !(epi.cf && source));
+                if (!source) { const uint32_t d = epi.deg_c[r]; xo[c] = (TX)(d ? nv / (double)d : 0.0); }
+            }
+            if (epi.d_active) {   // one atomic per workgroup
+                __shared__ unsigned wsum[P2_THREADS / 64];
+                for (int o = 32; o > 0; o >>= 1) act += __shfl_down(act, o);
+                if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = act;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned t = 0;
+                    for (int w = 0; w < P2_THREADS / 64; w++) t += wsum[w];
+                    if (t) atomicAdd(epi.d_active, (unsigned long long)t);
+                }
+            }
+            return;
+        }
+    }
     for (uint32_t i = threadIdx.x; i < rn; i += P2_THREADS) {
         T a = acc[i];
         if (a == neutral) continue;
@@ -500,6 +534,7 @@ struct gt_pb {
     uint32_t val_bytes = 0;
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice, largest chunk first
+    uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
     int val_kind = 0;          // 1: f32 messages of an f64 sum, 2: f64, 3: u32
@@ -508,7 +543,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -712,6 +747,15 @@ int gt_pb_build(gt_graph *g) {
         }
     }
     pb->nwork = (uint32_t)work.size();
+    {
+        std::vector<uint8_t> single(pb->nbins, 1);   // a bin without entries keeps y = 0: "single" with nothing to do... but
+        std::vector<uint32_t> parts(pb->nbins, 0);   // nobody would apply its rows, so only bins with exactly one workgroup count
+        for (const BinWork &w : work) parts[w.bin]++;
+        for (uint32_t b = 0; b < pb->nbins; b++) single[b] = parts[b] == 1;
+        for (BinWork &w : work) w.single = single[w.bin];
+        PB_MALLOC(pb->bin_single, pb->nbins);
+        PB_HIP(hipMemcpy(pb->bin_single, single.data(), pb->nbins, hipMemcpyHostToDevice));
+    }
     PB_MALLOC(pb->work, work.size() * sizeof(BinWork));
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
     if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
@@ -747,7 +791,7 @@ int gt_pb_build(gt_graph *g) {
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
-                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases) {
+                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see k_pb_scatter).
     const bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
     if (phases & GT_PB_PREPARE) {
@@ -767,15 +811,26 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     }
     if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
-        k_pb_gather<T, TV, IS_MIN><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y,
-                                                                    filter ? pb->active_prefix : nullptr);
+        const uint32_t *ap = filter ? pb->active_prefix : nullptr;
+        if constexpr (std::is_same<T, double>::value) {
+            if (epi && epi->x_f32)
+                k_pb_gather<T, TV, IS_MIN, 1><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+            else if (epi)
+                k_pb_gather<T, TV, IS_MIN, 2><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+            else
+                k_pb_gather<T, TV, IS_MIN, 0><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+        } else {
+            k_pb_gather<T, TV, IS_MIN, 0><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+        }
     }
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
 
+const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
+
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases) {
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -796,14 +851,14 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }
