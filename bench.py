@@ -202,6 +202,13 @@ def main():
     # IA + JA + x + y of the tile-row (on several ranks x / JA span the ncols_local columns the tile-row reads)
     ncols = i.nnzcols if world == 1 else i.ncols_local
     b_alg = 4 * i.nnz_local + 4 * (ncols + 1) + F * ncols + F * i.nnzrows
+    # one rank: the SpMV launch pair also runs PageRank's applicator + next messenger for the rows of the bins one
+    # phase-2 workgroup owns; its compulsory bytes per such row: rank read + write, changed flag, degree,
+    # row->column map, message = 8 + 8 + 1 + 4 + 4 + (4 | 8)
+    fused_rows = int(VR.stats.fused_apply_rows) if world == 1 else 0
+    b_fused = fused_rows * (25 + (4 if args.spmv == "pb_f32msg" else 8))
+    b_spmv = b_alg
+    b_alg += b_fused
     kernel_ms = spmv_ms / launches
     t = torch.tensor([dt, kernel_ms, float(b_alg)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -233,6 +240,7 @@ def main():
                                                   "pb_f32msg": "k_pb_scatter<double,float> + k_pb_gather<double,float> (one SpMV = this launch pair)",
                                                   "edge": "k_spmv_edge<GT_PLUS_F64>"}[args.spmv], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
+                     "algorithmic_bytes_spmv": float(b_spmv), "algorithmic_bytes_fused_apply": float(b_fused), "fused_apply_rows": fused_rows,
                      "kernel_ms": kernel_ms, "launches": launches},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

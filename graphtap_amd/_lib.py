@@ -49,7 +49,7 @@ class ProgramParams(C.Structure):
 
 class ExecStats(C.Structure):
     _fields_ = [("iterations", C.c_uint32), ("converged", C.c_uint32), ("seconds", C.c_double),
-                ("spmv_ms", C.c_double), ("spmv_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("spmv_ms", C.c_double), ("spmv_launches", C.c_uint32), ("fused_apply_rows", C.c_uint32),
                 ("scatter_gather_ms", C.c_double), ("combine_ms", C.c_double), ("apply_ms", C.c_double)]
 
 

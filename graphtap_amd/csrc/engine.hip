@@ -819,6 +819,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->iterations = p->iteration; stats->converged = p->converged;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
+        stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

@@ -535,6 +535,7 @@ struct gt_pb {
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice, largest chunk first
     uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
+    uint32_t rows_single = 0;           // rows of those bins
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
     int val_kind = 0;          // 1: f32 messages of an f64 sum, 2: f64, 3: u32
@@ -751,7 +752,10 @@ int gt_pb_build(gt_graph *g) {
         std::vector<uint8_t> single(pb->nbins, 1);   // a bin without entries keeps y = 0: "single" with nothing to do... but
         std::vector<uint32_t> parts(pb->nbins, 0);   // nobody would apply its rows, so only bins with exactly one workgroup count
         for (const BinWork &w : work) parts[w.bin]++;
-        for (uint32_t b = 0; b < pb->nbins; b++) single[b] = parts[b] == 1;
+        for (uint32_t b = 0; b < pb->nbins; b++) {
+            single[b] = parts[b] == 1;
+            if (single[b]) pb->rows_single += std::min<uint32_t>(R, nr - b * R);
+        }
         for (BinWork &w : work) w.single = single[w.bin];
         PB_MALLOC(pb->bin_single, pb->nbins);
         PB_HIP(hipMemcpy(pb->bin_single, single.data(), pb->nbins, hipMemcpyHostToDevice));
@@ -828,6 +832,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
 }
 
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
+uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
 
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {

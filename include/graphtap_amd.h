@@ -140,7 +140,8 @@ typedef struct gt_exec_stats {
     double seconds;        /* wall time of the iteration loop, device drained ("Execute time", vp:416-437) */
     double spmv_ms;        /* sum of SpMV kernel durations (HIP events on the handle's stream) */
     uint32_t spmv_launches;
-    uint32_t reserved;
+    uint32_t fused_apply_rows; /* PageRank: rows whose applicator ran inside each SpMV launch pair (the row bins one
+                                  phase-2 workgroup owns); 0 when nothing was fused */
     /* the reference's -DTIMING record (vp:2134-2152), host wall time of the three phases summed over the
      * iterations of this call; phases are enqueued asynchronously, so they only add up to `seconds` when the
      * library is asked to drain the stream after each phase (environment GRAPHTAP_TIMING=1) */
