@@ -81,6 +81,7 @@ SIGNATURES = {
     "gt_program_scatter_gather": (C.c_int, [_vp]),
     "gt_program_combine": (C.c_int, [_vp]),
     "gt_program_combine_slice": (C.c_int, [_vp, C.c_uint32]),
+    "gt_program_fuse_apply": (C.c_int, [_vp, C.c_uint32, C.c_int]),
     "gt_program_apply": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "gt_program_finish_converged": (C.c_int, [_vp]),
     "gt_program_iteration": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),

@@ -605,6 +605,17 @@ int gt_program_scatter_gather(gt_program *p) {
     return GT_OK;
 }
 
+// PageRank with apply armed to follow this combine (gt_program_execute, gt_program_fuse_apply): the epilogue phase 2 runs
+// for the row bins one workgroup owns. Returns false when nothing is to be fused.
+static bool fused_epilogue(gt_program *p, gt_pr_epilogue *epi) {
+    const gt_graph *g = p->g;
+    if (!(p->fuse_armed && p->prm.kind == GT_PR && g->spmv_variant != GT_SPMV_EDGE && g->pb != nullptr)) return false;
+    const bool cf = (p->prm.compression == GT_TCSC_CF);
+    *epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, g->R2C, p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
+                          cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr};
+    return true;
+}
+
 // slices [lo, hi) of the K = x_slices steps of one SpMV; the accumulators are complete after hi == K
 static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
     const gt_graph *g = p->g;
@@ -636,13 +647,8 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
             GT_HIP(hipEventRecord(e0, s));
         }
         gt_pr_epilogue epi{};
-        const bool fuse = p->fuse_armed && p->prm.kind == GT_PR && g->spmv_variant != GT_SPMV_EDGE && g->pb != nullptr;
-        if (fuse) {
-            const bool cf = (p->prm.compression == GT_TCSC_CF);
-            epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, g->R2C, p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
-                                 cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr};
-            if (p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
-        }
+        const bool fuse = hi >= K && fused_epilogue(p, &epi);
+        if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
         int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr);
         if (st != GT_OK) return st;
         p->fused = fuse;
@@ -679,8 +685,12 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
     }
     if (hi >= K) {
         for (uint32_t k = 0; k < K; k++) GT_HIP(hipStreamWaitEvent(s, p->slice_done[k], 0));
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2);
+        gt_pr_epilogue epi{};
+        const bool fuse = fused_epilogue(p, &epi);
+        if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2, fuse ? &epi : nullptr);
         if (st != GT_OK) return st;
+        p->fused = fuse;
         if (timed) { hipEvent_t e1; st = timing_event(&e1); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e1, s)); p->spmv_done++; }
     }
     return GT_OK;
@@ -693,6 +703,16 @@ int gt_program_combine_slice(gt_program *p, uint32_t k) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "combine before initialize");
     GT_REQUIRE(k < p->g->info.x_slices, GT_ERR_INVALID, "slice %u of %u", k, p->g->info.x_slices);
     return combine_impl(p, p->timing, k, k + 1);
+}
+static bool fuse_enabled() {
+    const char *e = getenv("GRAPHTAP_FUSE_APPLY");
+    return !(e != nullptr && atoi(e) == 0);   // on by default
+}
+int gt_program_fuse_apply(gt_program *p, uint32_t num_iterations, int want_active) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "fuse_apply before initialize");
+    p->fuse_armed = fuse_enabled() && p->prm.kind == GT_PR && !p->converged;
+    p->fuse_iters = num_iterations; p->fuse_count = want_active != 0;
+    return GT_OK;
 }
 int gt_program_enable_timing(gt_program *p, int on) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
@@ -789,7 +809,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
     // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
     const bool phase_timing = stats != nullptr && getenv("GRAPHTAP_TIMING") != nullptr;
-    const bool fuse_apply = !(getenv("GRAPHTAP_FUSE_APPLY") != nullptr && atoi(getenv("GRAPHTAP_FUSE_APPLY")) == 0);   // on by default
+    const bool fuse_apply = fuse_enabled();
     double t_sg = 0, t_cb = 0, t_ap = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc) -> int {

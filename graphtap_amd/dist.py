@@ -83,8 +83,11 @@ def run(engine, iters, group=None):
             engine._plan_verified = True
     pipelined = exchange and K > 1 and not _staged(x) and hasattr(engine, "combine_slice")
     converged = False
+    arm = getattr(engine, "arm_fused_apply", None) if not engine.column_accumulators else None
     while True:
         engine.scatter_gather()
+        if arm:
+            arm(iters, check)        # apply follows combine at once: the engine may fuse the two (PageRank)
         if pipelined:
             works = [exchange_slice(x, send, plan, s, group, async_op=True) for s in range(K)]
             for s in range(K):

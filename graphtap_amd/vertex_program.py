@@ -104,6 +104,10 @@ class _HipEngine:
     def combine_slice(self, k):
         check(lib().gt_program_combine_slice(self.prog._h, k))
 
+    def arm_fused_apply(self, iters, want_active):
+        """apply(iters, want_active) follows the next combine at once: phase 2 may run PageRank's applicator itself"""
+        check(lib().gt_program_fuse_apply(self.prog._h, iters, int(bool(want_active))))
+
     def apply(self, iters, want_active):
         a = C.c_uint64(0)
         check(lib().gt_program_apply(self.prog._h, iters, C.byref(a) if want_active else None))

@@ -235,6 +235,11 @@ int gt_program_combine(gt_program *p);
  * needs only slice k of x (all segments); the accumulators are complete after step K-1. Steps must be issued in
  * order 0..K-1. */
 int gt_program_combine_slice(gt_program *p, uint32_t k);
+/* Optional, PageRank only: promises that gt_program_apply(p, num_iterations, active != NULL) follows the next complete
+ * combine at once (nothing reads y in between). Phase 2 of that combine then applies the rows of the row bins one
+ * workgroup owns while their sums are still in LDS; the apply call finishes the rest. Results are the same with or
+ * without the call (environment GRAPHTAP_FUSE_APPLY=0 turns it into a no-op); gt_program_execute does this itself. */
+int gt_program_fuse_apply(gt_program *p, uint32_t num_iterations, int want_active);
 /* apply(), vp:1610-1802, then iteration++. active (nullable) receives the number of
  * owned vertices whose applicator returned true -- the local term of has_converged(),
  * vp:1885-1923 (regular rows only under GT_TCSC_CF); reading it waits for the stream. */

@@ -277,6 +277,8 @@ def _loopback_lockstep(progs, engs, iters):
     check = iters == 0
     while True:
         for e_ in engs: e_.scatter_gather()
+        if not engs[0].column_accumulators and engs[0].iteration % 3 != 1:   # like dist.run; skipped now and then: optional
+            for e_ in engs: e_.arm_fused_apply(iters, check)
         if engs[0].needs_x_exchange:   # the K all-to-alls of gt_graph_exchange_plan, by device copies
             xs = [e_.x_tensor() for e_ in engs]; sends = [e_.send_tensor() for e_ in engs]
             plans = [e_.exchange_plan() for e_ in engs]

@@ -28,6 +28,7 @@ _lib.check(L.gt_program_enable_timing(h, 1))
 K = G.info.x_slices
 def step():
     _lib.check(L.gt_program_scatter_gather(h))
+    _lib.check(L.gt_program_fuse_apply(h, 0x7fffffff, 0))   # as graphtap_amd/dist.py does (GRAPHTAP_FUSE_APPLY=0: no-op)
     if a.sliced:
         for k in range(K): _lib.check(L.gt_program_combine_slice(h, k))
     else:
