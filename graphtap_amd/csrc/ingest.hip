@@ -294,7 +294,10 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     uint32_t K = 1;
     if (p > 1) {
         const char *e = getenv("GRAPHTAP_X_SLICES");
-        K = e ? (uint32_t)atoi(e) : 2u;   // slicing is not free (engine.hip, combine_impl): two slices hide half of the exchange
+        // Slicing is not free (engine.hip, combine_impl: +0.025 ms per step at K = 2, +0.05 ms at K = 4 on a tile-row of 8)
+        // and hides (K-1)/K of the exchange: worth four slices while a rank receives tens of MB over one to three xGMI
+        // links (2 or 4 ranks), two at 8 ranks (6 MB per link).
+        K = e ? (uint32_t)atoi(e) : (p <= 4 ? 4u : 2u);
         if (K < 1) K = 1;
         if (K > 64) K = 64;
     }

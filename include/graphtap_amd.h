@@ -86,8 +86,8 @@ typedef struct gt_graph_info {
     uint64_t nnzrows_global, nnzcols_global;
     int32_t weighted;
     uint32_t regular, source_rows, sink_cols; /* owned-segment class counts (matrix.hpp:1125-1144) */
-    uint32_t x_slices;      /* K: the exchange of an iteration runs in K slices (1 on one rank; 2 by default on
-                               several, environment GRAPHTAP_X_SLICES at build time)                        */
+    uint32_t x_slices;      /* K: the exchange of an iteration runs in K slices (1 on one rank; 4 at 2-4 ranks and 2
+                               beyond by default, environment GRAPHTAP_X_SLICES at build time)                        */
     uint32_t slice_width;   /* T = ceil(S / K): compressed column j of any segment travels in slice j / T  */
     uint32_t ncols_local;   /* elements of the message vector x this handle's SpMV reads: S on one rank; on several
                                ranks only the columns the tile-row has an entry in, see gt_graph_exchange_plan */
