@@ -5,7 +5,7 @@
 // stream and every random access hits LDS:
 //
 //   phase 1  "scatter"   one workgroup per CHUNK of the column-major entry stream (a window of
-//            W = 8192 consecutive compressed columns, split every CH <= 2^20 entries): the window's messages
+//            W = 8192 consecutive compressed columns, split every CH <= 2^21 entries): the window's messages
 //            x[col0 .. col0+W) are staged in LDS (coalesced load), then for every entry, in
 //            (chunk, row-bin) order, VAL[k] = x[col] (+ w) is written at the entry's slot k of the
 //            row-bin-major value stream. A lane handles a QUAD of four consecutive entries: one 8-byte
@@ -54,13 +54,15 @@ namespace {
 constexpr int RB = GT_PB_ROW_BIN_BITS;  // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS
 constexpr uint32_t W = GT_PB_WINDOW;   // 8192 columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
-// Entries per chunk: large chunks make long runs (mean run ~300 entries at 2^20 on R-MAT-26), but the grid
-// must still be several times the 512 resident phase-1 workgroups: aim at >= ~1024 entry-limited chunks.
-static uint32_t ch_default(uint32_t nnz) {
+// Entries per chunk: large chunks make long runs and more same-row neighbours to pre-aggregate (R-MAT-26: 6.01 M runs and
+// 1.287 entries per output at 2^20, 5.62 M and 1.329 at 2^21, +4 % GTEPS; at 2^22 the largest chunk alone takes 1.9x the
+// even share of the 512 resident workgroups), but the grid must still be several times those 512: >= ~2048 chunks.
+static uint32_t ch_default(uint32_t nnz, uint32_t nwin) {
     const char *e = getenv("GRAPHTAP_PB_CH");
     if (e) return 1u << atoi(e);
+    if (nwin >= 2048) return 1u << 21;   // the windows alone give enough chunks: only split the hub windows
     uint32_t ch = 1u << 14;
-    while (ch < (1u << 20) && (uint64_t)ch * 2048 <= nnz) ch <<= 1;
+    while (ch < (1u << 21) && (uint64_t)ch * 2048 <= nnz) ch <<= 1;
     return ch;
 }
 constexpr uint32_t EPW = 1u << 19;     // value-stream slots per phase-2 workgroup: a bin below it keeps ONE workgroup, whose flush
@@ -584,7 +586,7 @@ int gt_pb_build(gt_graph *g) {
     while ((1u << binbits) < pb->nbins) binbits++;
     const uint32_t binmask = (1u << binbits) - 1;
     const uint32_t nwin = (ncols + W - 1) / W;
-    uint32_t ch = ch_default(nnz);
+    uint32_t ch = ch_default(nnz, nwin);
     DevBuf nsub, cbase;
     PB_ALLOC(nsub, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cbase, (uint64_t)(nwin + 1) * 4);
     uint32_t nchunks = 0;
