@@ -43,6 +43,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <type_traits>
 #include <vector>
@@ -54,13 +55,14 @@ namespace {
 constexpr int RB = GT_PB_ROW_BIN_BITS;  // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS
 constexpr uint32_t W = GT_PB_WINDOW;   // 8192 columns per window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
-// Entries per chunk: large chunks make long runs and more same-row neighbours to pre-aggregate (R-MAT-26: 6.01 M runs and
-// 1.287 entries per output at 2^20, 5.62 M and 1.329 at 2^21, +4 % GTEPS; at 2^22 the largest chunk alone takes 1.9x the
-// even share of the 512 resident workgroups), but the grid must still be several times those 512: >= ~2048 chunks.
+// Entries per chunk. A window is one chunk unless it holds more than `ch` entries; hub windows are cut by row bin (k_win_plan),
+// which leaves their runs whole, so `ch` only sets the granularity of the launch: 2^19 balances R-MAT-26 (4 269 chunks, the
+// largest 0.70 M entries; 2^18 ... 2^21 are within the noise, 2^19 best in alternating runs). Small graphs: the grid must
+// still be several times the 512 resident phase-1 workgroups, so `ch` shrinks until there are >= ~2048 chunks.
 static uint32_t ch_default(uint32_t nnz, uint32_t nwin) {
     const char *e = getenv("GRAPHTAP_PB_CH");
     if (e) return 1u << atoi(e);
-    if (nwin >= 2048) return 1u << 21;   // the windows alone give enough chunks: only split the hub windows
+    if (nwin >= 2048) return 1u << 19;   // the windows alone give enough chunks: only the hub windows are cut
     uint32_t ch = 1u << 14;
     while (ch < (1u << 21) && (uint64_t)ch * 2048 <= nnz) ch <<= 1;
     return ch;
@@ -97,33 +99,75 @@ struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes, k-slots in output unit
 struct BinWork { uint32_t bin, k0, k1, single, c_lo, c_hi, pad0, pad1; };   // [c_lo, c_hi]: chunks whose runs overlap [k0, k1)
 
 // ------------------------------------------------------------------ build kernels
-__global__ void k_win_counts(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t nwin, uint32_t ch, uint32_t *__restrict__ nsub) {
+// A window (W consecutive columns) is one chunk, unless it holds more than `ch` entries: a HUB window is cut into several
+// chunks. by_bins = 0: by position in the column-major stream (every chunk then has a piece of every run of the window).
+// by_bins = 1 (default): by ROW BIN -- consecutive bins are packed into chunks of ~n/ceil(n/ch) entries, so every run holds
+// ALL entries its window has in that bin: as few and as long runs as the window allows and every same-row neighbour to
+// pre-aggregate (R-MAT-26: 5.41 M runs / 1.39 entries per slot instead of 5.62 M / 1.33). A bin that alone exceeds 1.5x
+// the chunk size (hub rows x hub columns) gets m chunks of its own and its entries go to them by column mod m.
+// plan[h * nbins + bin] = first chunk of the bin inside its window | (m << 20); h = hub index of the window.
+constexpr uint32_t PLAN_SUB_MASK = (1u << 20) - 1;
+__global__ void k_win_sizes(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t nwin, uint32_t ch, uint32_t *__restrict__ nsub,
+                            uint32_t *__restrict__ hubflag) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x) {
         uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
         uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols];
-        nsub[q] = (e1 - e0 + ch - 1) / ch;
+        nsub[q] = (e1 - e0 + ch - 1) / ch;          // final for ordinary windows and for the split by position
+        hubflag[q] = (e1 - e0 > ch) ? 1u : 0u;
     }
 }
-__global__ void k_fill_chunks(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t nwin, uint32_t ch,
-                              const uint32_t *__restrict__ cbase, uint32_t *__restrict__ ce0, uint32_t *__restrict__ ce1,
-                              uint32_t *__restrict__ ccol0) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x) {
-        uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
-        uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols];
-        uint32_t n = (e1 - e0 + ch - 1) / ch, base = cbase[q];
-        for (uint32_t s = 0; s < n; s++) {
-            uint64_t a = (uint64_t)e0 + (uint64_t)s * ch, b = a + ch;
-            ce0[base + s] = (uint32_t)a; ce1[base + s] = (uint32_t)(b < e1 ? b : e1); ccol0[base + s] = (uint32_t)c0;
+__global__ void k_win_plan(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ IA, uint32_t ch, uint32_t nbins,
+                           const uint32_t *__restrict__ hubflag, const uint32_t *__restrict__ hubidx, uint32_t *__restrict__ plan,
+                           uint32_t *__restrict__ nsub) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t q = blockIdx.x;
+    if (!hubflag[q]) return;
+    const uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
+    const uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols], n = e1 - e0;
+    for (uint32_t i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (uint64_t e = (uint64_t)e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&hist[IA[e] >> RB], 1u);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const uint32_t ns = (n + ch - 1) / ch, target = (n + ns - 1) / ns;
+    uint32_t *pl = plan + (uint64_t)hubidx[q] * nbins;
+    uint32_t sub = 0, acc = 0;
+    for (uint32_t b = 0; b < nbins; b++) {
+        const uint32_t h = hist[b];
+        if (h > target + target / 2) {                       // a bin for several chunks of its own
+            if (acc) { sub++; acc = 0; }
+            uint32_t m = (h + target - 1) / target;
+            if (m > 4095) m = 4095;
+            pl[b] = sub | (m << 20); sub += m;
+        } else {
+            if (acc && acc + h > target + target / 4) { sub++; acc = 0; }
+            pl[b] = sub | (1u << 20); acc += h;
         }
     }
+    if (acc) sub++;
+    nsub[q] = sub;
+}
+__global__ void k_fill_chunks(uint32_t nwin, const uint32_t *__restrict__ nsub, const uint32_t *__restrict__ cbase, uint32_t *__restrict__ ccol0) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x)
+        for (uint32_t k = 0; k < nsub[q]; k++) ccol0[cbase[q] + k] = q * W;
 }
 // sort key of every entry: (chunk, row bin, row inside the bin) -> runs come out sorted by (row, col)
-__global__ void k_keys(const uint32_t *__restrict__ ce0, const uint32_t *__restrict__ ce1, const uint32_t *__restrict__ IA,
-                       int binbits, uint64_t *__restrict__ key, uint32_t *__restrict__ idx) {
-    const uint32_t c = blockIdx.x;
-    for (uint64_t e = (uint64_t)ce0[c] + threadIdx.x; e < ce1[c]; e += blockDim.x) {
-        const uint32_t r = IA[e];
-        key[e] = ((((uint64_t)c << binbits) | (r >> RB)) << RB) | (r & (R - 1));
+__global__ void k_keys(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ cbase, uint32_t ch,
+                       const uint32_t *__restrict__ hubflag, const uint32_t *__restrict__ hubidx, const uint32_t *__restrict__ plan, uint32_t nbins,
+                       const uint32_t *__restrict__ IA, const uint32_t *__restrict__ JI, int binbits,
+                       uint64_t *__restrict__ key, uint32_t *__restrict__ idx) {
+    const uint32_t q = blockIdx.x;   // window
+    const uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
+    const uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols];
+    const uint32_t base = cbase[q];
+    const bool hub = hubflag[q] != 0;
+    const uint32_t *__restrict__ pl = (hub && plan) ? plan + (uint64_t)hubidx[q] * nbins : nullptr;
+    for (uint64_t e = (uint64_t)e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const uint32_t r = IA[e], bin = r >> RB;
+        uint32_t sub = 0;
+        if (pl) { const uint32_t p = pl[bin], m = p >> 20; sub = (p & PLAN_SUB_MASK) + (m > 1 ? (JI[e] - (uint32_t)c0) % m : 0u); }
+        else if (hub) sub = (uint32_t)((e - e0) / ch);
+        key[e] = ((((uint64_t)(base + sub) << binbits) | bin) << RB) | (r & (R - 1));
         idx[e] = (uint32_t)e;
     }
 }
@@ -587,12 +631,25 @@ int gt_pb_build(gt_graph *g) {
     const uint32_t binmask = (1u << binbits) - 1;
     const uint32_t nwin = (ncols + W - 1) / W;
     uint32_t ch = ch_default(nnz, nwin);
-    DevBuf nsub, cbase;
+    DevBuf nsub, cbase, hubflag, hubidx, plan;
     PB_ALLOC(nsub, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cbase, (uint64_t)(nwin + 1) * 4);
+    PB_ALLOC(hubflag, (uint64_t)(nwin + 1) * 4); PB_ALLOC(hubidx, (uint64_t)(nwin + 1) * 4);
+    const char *split = getenv("GRAPHTAP_PB_SPLIT");
+    const bool by_bins = !(split && strcmp(split, "entries") == 0) && (uint64_t)pb->nbins * 4 <= 64 * 1024;   // bin histogram in LDS
     uint32_t nchunks = 0;
     for (;;) {  // chunk ids must fit above the bin bits of a 32-bit sort key
         PB_HIP(hipMemsetAsync(nsub.p, 0, (uint64_t)(nwin + 1) * 4, s));
-        k_win_counts<<<grid_for(nwin), TPB, 0, s>>>(g->JA, ncols, nwin, ch, nsub.as<uint32_t>());
+        PB_HIP(hipMemsetAsync(hubflag.p, 0, (uint64_t)(nwin + 1) * 4, s));
+        k_win_sizes<<<grid_for(nwin), TPB, 0, s>>>(g->JA, ncols, nwin, ch, nsub.as<uint32_t>(), hubflag.as<uint32_t>());
+        if (by_bins) {
+            PB_SCAN_EXCL(hubflag.as<uint32_t>(), hubidx.as<uint32_t>(), nwin + 1);
+            uint32_t nhub = 0;
+            PB_HIP(hipMemcpy(&nhub, hubidx.as<uint32_t>() + nwin, 4, hipMemcpyDeviceToHost));
+            if (plan.p) { (void)hipFree(plan.p); plan.p = nullptr; }
+            PB_ALLOC(plan, (uint64_t)std::max(nhub, 1u) * pb->nbins * 4);
+            if (nhub) k_win_plan<<<nwin, TPB, pb->nbins * 4, s>>>(g->JA, ncols, g->IA, ch, pb->nbins, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
+                                                                 plan.as<uint32_t>(), nsub.as<uint32_t>());
+        }
         PB_SCAN_EXCL(nsub.as<uint32_t>(), cbase.as<uint32_t>(), nwin + 1);
         PB_HIP(hipMemcpy(&nchunks, cbase.as<uint32_t>() + nwin, 4, hipMemcpyDeviceToHost));
         if ((uint64_t)nchunks < (1ull << (32 - binbits))) break;
@@ -601,16 +658,15 @@ int gt_pb_build(gt_graph *g) {
     int chunkbits = 1;
     while ((1ull << chunkbits) < nchunks) chunkbits++;
     pb->nchunks = nchunks;
-    DevBuf ce0, ce1;
-    PB_ALLOC(ce0, (uint64_t)nchunks * 4); PB_ALLOC(ce1, (uint64_t)nchunks * 4);
     PB_MALLOC(pb->cv0, (uint64_t)nchunks * 4); PB_MALLOC(pb->cv1, (uint64_t)nchunks * 4); PB_MALLOC(pb->ccol0, (uint64_t)nchunks * 4);
-    k_fill_chunks<<<grid_for(nwin), TPB, 0, s>>>(g->JA, ncols, nwin, ch, cbase.as<uint32_t>(), ce0.as<uint32_t>(), ce1.as<uint32_t>(), pb->ccol0);
+    k_fill_chunks<<<grid_for(nwin), TPB, 0, s>>>(nwin, nsub.as<uint32_t>(), cbase.as<uint32_t>(), pb->ccol0);
 
     // v-order: entries sorted by (chunk, bin, row); the radix sort is stable, so inside a run rows ascend and,
     // for equal rows, the column-major input order (ascending column) survives
     DevBuf key, key2, idx, idx2, rkey, sidb;
     PB_ALLOC(key, (uint64_t)nnz * 8); PB_ALLOC(key2, (uint64_t)nnz * 8); PB_ALLOC(idx, (uint64_t)nnz * 4); PB_ALLOC(idx2, (uint64_t)nnz * 4);
-    k_keys<<<nchunks, TPB, 0, s>>>(ce0.as<uint32_t>(), ce1.as<uint32_t>(), g->IA, binbits, key.as<uint64_t>(), idx.as<uint32_t>());
+    k_keys<<<nwin, TPB, 0, s>>>(g->JA, ncols, cbase.as<uint32_t>(), ch, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
+                                by_bins ? plan.as<uint32_t>() : nullptr, pb->nbins, g->IA, g->JI, binbits, key.as<uint64_t>(), idx.as<uint32_t>());
     hipcub::DoubleBuffer<uint64_t> dk(key.as<uint64_t>(), key2.as<uint64_t>());
     hipcub::DoubleBuffer<uint32_t> di(idx.as<uint32_t>(), idx2.as<uint32_t>());
     {
