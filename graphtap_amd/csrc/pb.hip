@@ -116,36 +116,42 @@ __global__ void k_win_sizes(const uint32_t *__restrict__ JA, uint32_t ncols, uin
         hubflag[q] = (e1 - e0 > ch) ? 1u : 0u;
     }
 }
-__global__ void k_win_plan(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ IA, uint32_t ch, uint32_t nbins,
-                           const uint32_t *__restrict__ hubflag, const uint32_t *__restrict__ hubidx, uint32_t *__restrict__ plan,
-                           uint32_t *__restrict__ nsub) {
-    extern __shared__ uint32_t hist[];
+// entries of every hub window per row bin, counted into plan[] (several blocks per window: a hub window holds millions)
+__global__ void k_win_hist(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ IA, uint32_t nbins,
+                           const uint32_t *__restrict__ hubflag, const uint32_t *__restrict__ hubidx, uint32_t *__restrict__ plan) {
     const uint32_t q = blockIdx.x;
     if (!hubflag[q]) return;
     const uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
-    const uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols], n = e1 - e0;
-    for (uint32_t i = threadIdx.x; i < nbins; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    for (uint64_t e = (uint64_t)e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&hist[IA[e] >> RB], 1u);
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const uint32_t ns = (n + ch - 1) / ch, target = (n + ns - 1) / ns;
-    uint32_t *pl = plan + (uint64_t)hubidx[q] * nbins;
-    uint32_t sub = 0, acc = 0;
-    for (uint32_t b = 0; b < nbins; b++) {
-        const uint32_t h = hist[b];
-        if (h > target + target / 2) {                       // a bin for several chunks of its own
-            if (acc) { sub++; acc = 0; }
-            uint32_t m = (h + target - 1) / target;
-            if (m > 4095) m = 4095;
-            pl[b] = sub | (m << 20); sub += m;
-        } else {
-            if (acc && acc + h > target + target / 4) { sub++; acc = 0; }
-            pl[b] = sub | (1u << 20); acc += h;
+    const uint32_t e0 = JA[c0 < ncols ? c0 : ncols], e1 = JA[c1 < ncols ? c1 : ncols];
+    uint32_t *h = plan + (uint64_t)hubidx[q] * nbins;
+    for (uint64_t e = (uint64_t)e0 + blockIdx.y * blockDim.x + threadIdx.x; e < e1; e += (uint64_t)blockDim.x * gridDim.y) atomicAdd(&h[IA[e] >> RB], 1u);
+}
+// counts -> plan, in place; one thread per hub window (a few thousand bins each)
+__global__ void k_win_plan(const uint32_t *__restrict__ JA, uint32_t ncols, uint32_t nwin, uint32_t ch, uint32_t nbins,
+                           const uint32_t *__restrict__ hubflag, const uint32_t *__restrict__ hubidx, uint32_t *__restrict__ plan,
+                           uint32_t *__restrict__ nsub) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x) {
+        if (!hubflag[q]) continue;
+        const uint64_t c0 = (uint64_t)q * W, c1 = c0 + W;
+        const uint32_t n = JA[c1 < ncols ? c1 : ncols] - JA[c0 < ncols ? c0 : ncols];
+        const uint32_t ns = (n + ch - 1) / ch, target = (n + ns - 1) / ns;
+        uint32_t *pl = plan + (uint64_t)hubidx[q] * nbins;
+        uint32_t sub = 0, acc = 0;
+        for (uint32_t b = 0; b < nbins; b++) {
+            const uint32_t h = pl[b];
+            if (h > target + target / 2) {                       // a bin for several chunks of its own
+                if (acc) { sub++; acc = 0; }
+                uint32_t m = (h + target - 1) / target;
+                if (m > 4095) m = 4095;
+                pl[b] = sub | (m << 20); sub += m;
+            } else {
+                if (acc && acc + h > target + target / 4) { sub++; acc = 0; }
+                pl[b] = sub | (1u << 20); acc += h;
+            }
         }
+        if (acc) sub++;
+        nsub[q] = sub;
     }
-    if (acc) sub++;
-    nsub[q] = sub;
 }
 __global__ void k_fill_chunks(uint32_t nwin, const uint32_t *__restrict__ nsub, const uint32_t *__restrict__ cbase, uint32_t *__restrict__ ccol0) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x)
@@ -162,7 +168,7 @@ __global__ void k_keys(const uint32_t *__restrict__ JA, uint32_t ncols, const ui
     const uint32_t base = cbase[q];
     const bool hub = hubflag[q] != 0;
     const uint32_t *__restrict__ pl = (hub && plan) ? plan + (uint64_t)hubidx[q] * nbins : nullptr;
-    for (uint64_t e = (uint64_t)e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    for (uint64_t e = (uint64_t)e0 + blockIdx.y * blockDim.x + threadIdx.x; e < e1; e += (uint64_t)blockDim.x * gridDim.y) {
         const uint32_t r = IA[e], bin = r >> RB;
         uint32_t sub = 0;
         if (pl) { const uint32_t p = pl[bin], m = p >> 20; sub = (p & PLAN_SUB_MASK) + (m > 1 ? (JI[e] - (uint32_t)c0) % m : 0u); }
@@ -635,7 +641,7 @@ int gt_pb_build(gt_graph *g) {
     PB_ALLOC(nsub, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cbase, (uint64_t)(nwin + 1) * 4);
     PB_ALLOC(hubflag, (uint64_t)(nwin + 1) * 4); PB_ALLOC(hubidx, (uint64_t)(nwin + 1) * 4);
     const char *split = getenv("GRAPHTAP_PB_SPLIT");
-    const bool by_bins = !(split && strcmp(split, "entries") == 0) && (uint64_t)pb->nbins * 4 <= 64 * 1024;   // bin histogram in LDS
+    const bool by_bins = !(split && strcmp(split, "entries") == 0);
     uint32_t nchunks = 0;
     for (;;) {  // chunk ids must fit above the bin bits of a 32-bit sort key
         PB_HIP(hipMemsetAsync(nsub.p, 0, (uint64_t)(nwin + 1) * 4, s));
@@ -647,8 +653,12 @@ int gt_pb_build(gt_graph *g) {
             PB_HIP(hipMemcpy(&nhub, hubidx.as<uint32_t>() + nwin, 4, hipMemcpyDeviceToHost));
             if (plan.p) { (void)hipFree(plan.p); plan.p = nullptr; }
             PB_ALLOC(plan, (uint64_t)std::max(nhub, 1u) * pb->nbins * 4);
-            if (nhub) k_win_plan<<<nwin, TPB, pb->nbins * 4, s>>>(g->JA, ncols, g->IA, ch, pb->nbins, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
-                                                                 plan.as<uint32_t>(), nsub.as<uint32_t>());
+            if (nhub) {
+                PB_HIP(hipMemsetAsync(plan.p, 0, (uint64_t)nhub * pb->nbins * 4, s));
+                k_win_hist<<<dim3(nwin, 16), TPB, 0, s>>>(g->JA, ncols, g->IA, pb->nbins, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(), plan.as<uint32_t>());
+                k_win_plan<<<grid_for(nwin), TPB, 0, s>>>(g->JA, ncols, nwin, ch, pb->nbins, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
+                                                         plan.as<uint32_t>(), nsub.as<uint32_t>());
+            }
         }
         PB_SCAN_EXCL(nsub.as<uint32_t>(), cbase.as<uint32_t>(), nwin + 1);
         PB_HIP(hipMemcpy(&nchunks, cbase.as<uint32_t>() + nwin, 4, hipMemcpyDeviceToHost));
@@ -665,7 +675,7 @@ int gt_pb_build(gt_graph *g) {
     // for equal rows, the column-major input order (ascending column) survives
     DevBuf key, key2, idx, idx2, rkey, sidb;
     PB_ALLOC(key, (uint64_t)nnz * 8); PB_ALLOC(key2, (uint64_t)nnz * 8); PB_ALLOC(idx, (uint64_t)nnz * 4); PB_ALLOC(idx2, (uint64_t)nnz * 4);
-    k_keys<<<nwin, TPB, 0, s>>>(g->JA, ncols, cbase.as<uint32_t>(), ch, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
+    k_keys<<<dim3(nwin, 8), TPB, 0, s>>>(g->JA, ncols, cbase.as<uint32_t>(), ch, hubflag.as<uint32_t>(), hubidx.as<uint32_t>(),
                                 by_bins ? plan.as<uint32_t>() : nullptr, pb->nbins, g->IA, g->JI, binbits, key.as<uint64_t>(), idx.as<uint32_t>());
     hipcub::DoubleBuffer<uint64_t> dk(key.as<uint64_t>(), key2.as<uint64_t>());
     hipcub::DoubleBuffer<uint32_t> di(idx.as<uint32_t>(), idx2.as<uint32_t>());
