@@ -21,9 +21,9 @@
 //            when it was split).
 //
 // A RUN is the set of entries of one (chunk, bin) pair; it is contiguous in both orders and, inside a run,
-// entries are sorted by (row, col). Phase 1 PRE-AGGREGATES: consecutive entries of a quad that hit the same
-// row are combined (+ or min) in registers and leave ONE value, so the value stream and LROW have one slot
-// per (quad, row) group instead of one per entry (R-MAT-26: 1.07 G entries -> see [pb] stats). Runs are
+// entries are sorted by (row, col). Phase 1 PRE-AGGREGATES: consecutive entries of a lane pair (8 entries) that hit
+// the same row are combined (+ or min) in registers and leave ONE value, so the value stream and LROW have one slot
+// per (lane pair, row) group instead of one per entry (R-MAT-26: 1.07 G entries -> see [pb] stats). Runs are
 // padded to a multiple of four entries in the v-order and to a multiple of four outputs in the k-order (pad
 // inputs read the neutral message from a spare LDS slot; pad outputs are pre-filled with the neutral value
 // and target row 0 of the bin: no effect), so quads never straddle runs and every access is aligned.
@@ -75,6 +75,8 @@ constexpr int P2_THREADS = 1024;
 #define GT_P2_U 2
 #endif
 constexpr int P2_U = GT_P2_U;            // quads in flight per lane in phase 2
+constexpr uint32_t AGG_MASK = 7;        // entries of the v-order that may share an output: 2 lanes x 4 (R-MAT-26: 1.40 entries per
+                                       // output with 4, 1.50 with 8, 1.56 with 16, 1.62 without a limit)
 constexpr uint16_t HEAD = 0x8000;
 constexpr uint16_t COLMASK = 0x3FFF;
 constexpr uint16_t GEND = 0x4000;      // last entry of its (quad, row) group
@@ -251,17 +253,30 @@ __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nru
         cv0[c] = pvstart[a]; cv1[c] = pvstart[b];
     }
 }
-// E[pv] = 1 when the entry at padded v-position pv is the last of its (quad, row) group
+// E[pv] = 1 when the entry at padded v-position pv is the last of its (lane pair, row) group: a group is a maximal stretch of
+// one row inside one run and inside one aligned block of 8 entries (two lanes x four entries of phase 1)
 __global__ void k_group_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n,
                              const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart,
                              uint32_t *__restrict__ E) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = sid[v] - 1, o = (uint32_t)v - vstart[s], pv = pvstart[s] + o;
         const bool last_of_run = (o + 1 == len[s]);
-        const bool last_of_quad = ((pv & 3) == 3);
+        const bool last_of_quad = ((pv & AGG_MASK) == AGG_MASK);
         const bool row_changes = !last_of_run && ((key64[v + 1] & (R - 1)) != (key64[v] & (R - 1)));
         E[pv] = (last_of_run || last_of_quad || row_changes) ? 1u : 0u;
     }
+}
+// [pb] stats: how many outputs there would be if groups could span 2^k consecutive entries of the v-order (mask = 2^k - 1)
+__global__ void k_count_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n, const uint32_t *__restrict__ vstart,
+                             const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart, uint32_t mask, unsigned long long *__restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = sid[v] - 1, o = (uint32_t)v - vstart[s], pv = pvstart[s] + o;
+        const bool last_of_run = (o + 1 == len[s]);
+        c += (last_of_run || (pv & mask) == mask || ((key64[v + 1] & (R - 1)) != (key64[v] & (R - 1))));
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 // outputs of run s = X[pvstart[s+1]] - X[pvstart[s]] (X = exclusive scan of E), padded to a multiple of 4
 __global__ void k_run_outputs(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ X, uint32_t nrun,
@@ -358,6 +373,19 @@ template <> struct Msg<double, double> { static __device__ __forceinline__ doubl
 template <> struct Msg<double, float> { static __device__ __forceinline__ float val(float x, uint32_t) { return x; } };
 template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
 
+// value of lane - 1 (inside a row of 16 lanes; only odd lanes use it)
+template <class TV> __device__ __forceinline__ TV dpp_shr1(TV v) {
+    if constexpr (sizeof(TV) == 8) {
+        const unsigned long long u = __double_as_longlong((double)v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x111, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x111, 0xf, 0xf, true);
+        return (TV)__longlong_as_double(((unsigned long long)hi << 32) | lo);
+    } else if constexpr (std::is_same<TV, float>::value) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    } else {
+        return (TV)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    }
+}
 template <class TV> struct alignas(sizeof(TV) * 4 > 16 ? 16 : sizeof(TV) * 4) V4 { TV a[4]; };
 struct alignas(8) C4 { uint16_t c[4]; };
 struct alignas(16) W4 { uint32_t w[4]; };
@@ -461,10 +489,18 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
                v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
+            // pairs of lanes: what the even lane's quad leaves open after its last group end (all of it when it has none)
+            // continues in the odd lane's first group -- one DPP hop, no LDS
+            TV tail = v3;
+            bool open = !e2;
+            tail = open ? comb(v2, tail) : tail; open = open && !e1;
+            tail = open ? comb(v1, tail) : tail; open = open && !e0;
+            tail = open ? comb(v0, tail) : tail;
+            const TV carry = dpp_shr1<TV>(e3 ? (IS_MIN ? (TV)GT_INF : (TV)0) : tail);
             SV *st = stage[wave];
             const uint32_t dump = 256 + lane;
             __builtin_amdgcn_wave_barrier();
-            TV acc = v0;
+            TV acc = (lane & 1) ? comb(carry, v0) : v0;
             uint32_t pos = pex;
             st[e0 ? pos : dump] = SV{acc, pos + delta};
             acc = e0 ? v1 : comb(acc, v1); pos += e0 ? 1u : 0u;
@@ -761,8 +797,15 @@ int gt_pb_build(gt_graph *g) {
         unsigned long long uq = 0; PB_HIP(hipMemcpy(&uq, cntb.p, 8, hipMemcpyDeviceToHost));
         fprintf(stderr, "[pb] distinct (run,row) groups: %llu of %u entries (factor %.3f)\n", uq, nnz, (double)nnz / uq);
     }
-    if (getenv("GRAPHTAP_PB_STATS"))
+    if (getenv("GRAPHTAP_PB_STATS")) {
         fprintf(stderr, "[pb] value-stream slots after pre-aggregation: %u for %u entries (factor %.3f)\n", nout, nnz, (double)nnz / nout);
+        for (uint32_t mask : {3u, 7u, 15u, 63u, 255u}) {
+            DevBuf cb; PB_ALLOC(cb, 8); PB_HIP(hipMemsetAsync(cb.p, 0, 8, s));
+            k_count_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), mask, cb.as<unsigned long long>());
+            unsigned long long c = 0; PB_HIP(hipMemcpy(&c, cb.p, 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pb] groups of up to %u consecutive entries: %llu outputs (factor %.3f)\n", mask + 1, c, (double)nnz / c);
+        }
+    }
     k_scatter_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), kscan.as<uint32_t>(), nrun, pkstart.as<uint32_t>());
     DevBuf binoff; PB_ALLOC(binoff, (uint64_t)(pb->nbins + 1) * 4);
     k_bin_offsets<<<grid_for(pb->nbins + 1), TPB, 0, s>>>(runbin_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun, nout, pb->nbins, binoff.as<uint32_t>());
