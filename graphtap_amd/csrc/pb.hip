@@ -850,7 +850,11 @@ int gt_pb_build(gt_graph *g) {
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
     std::vector<BinWork> work;
-    const uint64_t epw = getenv("GRAPHTAP_PB_EPW") ? (1ull << atoi(getenv("GRAPHTAP_PB_EPW"))) : EPW;
+    // slots per phase-2 workgroup: 2^19, but a small graph must still give every CU work (R-MAT 22 has 123 row bins for
+    // 256 CUs): at least ~200 workgroups (more, smaller ones lose the fused applicator: R-MAT 22 -7 % at 2^16)
+    uint64_t epw = EPW;
+    while (epw > (1u << 14) && (uint64_t)nout / epw < 192) epw >>= 1;
+    if (getenv("GRAPHTAP_PB_EPW")) epw = 1ull << atoi(getenv("GRAPHTAP_PB_EPW"));
     for (uint32_t b = 0; b < pb->nbins; b++) {
         uint64_t n = hoff[b + 1] - hoff[b];
         if (!n) continue;
