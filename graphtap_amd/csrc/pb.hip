@@ -677,11 +677,7 @@ int gt_pb_build(gt_graph *g) {
     PB_ALLOC(nsub, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cbase, (uint64_t)(nwin + 1) * 4);
     PB_ALLOC(hubflag, (uint64_t)(nwin + 1) * 4); PB_ALLOC(hubidx, (uint64_t)(nwin + 1) * 4);
     const char *split = getenv("GRAPHTAP_PB_SPLIT");
-    // Whole runs are long runs: at R-MAT 22 (2 200 entries per window x bin) they put hundreds of consecutive value-stream
-    // slots on the same hub row, and phase 2 serialises on same-address LDS atomics (0.124 -> 0.200 ms while phase 1 gains
-    // 0.011). Cut by bins where runs are short enough for that not to matter (R-MAT 24: 560 entries, +12 %; 26: 200, +10 %).
-    const bool dense = (uint64_t)nnz / std::max<uint64_t>(1, (uint64_t)nwin * pb->nbins) >= 1024;
-    const bool by_bins = split ? strcmp(split, "entries") != 0 : !dense;
+    const bool by_bins = !(split && strcmp(split, "entries") == 0);
     uint32_t nchunks = 0;
     for (;;) {  // chunk ids must fit above the bin bits of a 32-bit sort key
         PB_HIP(hipMemsetAsync(nsub.p, 0, (uint64_t)(nwin + 1) * 4, s));
