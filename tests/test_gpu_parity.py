@@ -601,6 +601,40 @@ def test_random_graphs_all_programs_against_oracle(gt, O, seed):
     V.free(); G.free()
 
 
+@pytest.mark.parametrize("shape", ["star", "block", "hub_rows_hub_cols"])
+def test_adversarial_shapes_against_oracle(gt, O, shape):
+    """Shapes that stress the propagation-blocking build: one (window, row bin) cell far above the chunk size (cut by
+    column residue), same-row stretches of hundreds of entries (lane-pair aggregation, long runs), hub windows cut by
+    row bin. PageRank to 1e-6, BFS / CC / SSSP bit for bit."""
+    rng = np.random.RandomState(7)
+    if shape == "star":            # vertex 0 <-> everybody, twice the ids of one window
+        nv = 40000
+        k = np.arange(1, nv, dtype=np.uint32)
+        e = np.concatenate([np.stack([np.zeros_like(k), k], 1), np.stack([k, np.zeros_like(k)], 1)])
+    elif shape == "block":         # a dense 600 x 600 block: 360 000 entries in one (window, bin) cell
+        nv = 30000
+        a, b = np.meshgrid(np.arange(600, dtype=np.uint32), np.arange(600, dtype=np.uint32) + 100)
+        e = np.stack([a.ravel(), b.ravel()], 1)
+        e = np.concatenate([e, rng.randint(0, nv, size=(20000, 2)).astype(np.uint32)])
+    else:                          # 40 hub rows x 40 hub columns carry most of 400 000 entries
+        nv = 60000
+        hubs = rng.randint(0, nv, size=40).astype(np.uint32)
+        e = rng.randint(0, nv, size=(400000, 2)).astype(np.uint32)
+        m1, m2 = rng.rand(len(e)) < 0.5, rng.rand(len(e)) < 0.5
+        e[m1, 0] = hubs[rng.randint(0, 40, size=m1.sum())]; e[m2, 1] = hubs[rng.randint(0, 40, size=m2.sum())]
+    e = np.ascontiguousarray(e, dtype=np.uint32)
+    w = np.concatenate([e, rng.randint(1, 129, size=(len(e), 1)).astype(np.uint32)], axis=1)
+    root = int(e[0, 0])
+    ref = O.run_app("pr", e, nv, iters=6); r = run_pr(gt, e, nv, 6)
+    assert (r["degree"] == ref["degree"]).all() and np.allclose(r["rank"], ref["rank"], rtol=PR_RTOL, atol=0)
+    ref = O.run_app("bfs", e, nv, root=root); r = run_min(gt, "bfs", e, nv, root)
+    assert (r["parent"] == ref["parent"]).all() and (r["hops"] == ref["hops"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("cc", e, nv); r = run_min(gt, "cc", e, nv)
+    assert (r["label"] == ref["label"]).all() and r["iterations"] == ref["iterations"]
+    ref = O.run_app("sssp", w, nv, root=root); r = run_min(gt, "sssp", w, nv, root)
+    assert (r["distance"] == ref["distance"]).all() and r["iterations"] == ref["iterations"]
+
+
 def test_bfs_cc_sssp_properties_at_rmat20(gt):
     """Size-independent properties (R-MAT 20 symmetrised: ~32 M stored entries), checked on
     the host against the edge list itself: BFS parent/hops consistency (parent is a neighbour one level up, the
