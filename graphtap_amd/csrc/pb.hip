@@ -31,7 +31,7 @@
 //   LCOL[v]  u16  v-order = runs sorted by (chunk, bin), entries inside by (row, col); bits 0-13: col - col0
 //                 (8192 = pad), bit 14: last entry of its (quad, row) group, bit 15: first entry of a run
 //   LROW[k]  u16  k-order = outputs, runs sorted by (bin, chunk); row & (R-1)
-//   WT[v]    u32  weights in v-order (min-plus only)
+//   WT[v]    u8 / u16 / u32 (the narrowest the largest weight fits) weights in v-order (min-plus only)
 //   G[g]     32 B per 256 entries of the v-order: the k-slot of lane 0's first output and, for the first six
 //                 run heads of the group, (k-slot of the run - outputs of the group before the head), so that no
 //                 load of phase 1 depends on another load and a lane gets its slots with one ds_bpermute
@@ -288,13 +288,13 @@ __global__ void k_static_streams(const uint64_t *__restrict__ key64, const uint3
                                  uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ JI,
                                  const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ pvstart,
                                  const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ E, const uint32_t *__restrict__ X,
-                                 uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW, uint32_t *__restrict__ WT) {
+                                 uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW, void *__restrict__ WT, int wt_bytes) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t e = idx[v], c = (uint32_t)(key64[v] >> (RB + binbits)), s = sid[v] - 1, o = (uint32_t)v - vstart[s];
         const uint32_t pv = pvstart[s] + o, ge = E[pv];
         LCOL[pv] = (uint16_t)((JI[e] - ccol0[c]) | (ge ? GEND : 0) | (o == 0 ? HEAD : 0));
         if (ge) LROW[pkstart[s] + (X[pv] - X[pvstart[s]])] = (uint16_t)(key64[v] & (R - 1));
-        if (WT) WT[pv] = A[e];
+        if (WT) { if (wt_bytes == 1) ((uint8_t *)WT)[pv] = (uint8_t)A[e]; else if (wt_bytes == 2) ((uint16_t *)WT)[pv] = (uint16_t)A[e]; else ((uint32_t *)WT)[pv] = A[e]; }
     }
 }
 // Group table: one record per 256 padded entries (64 lanes x 4) of the v-order, k-slots in output units.
@@ -388,12 +388,18 @@ template <class TV> __device__ __forceinline__ TV dpp_shr1(TV v) {
 }
 template <class TV> struct alignas(sizeof(TV) * 4 > 16 ? 16 : sizeof(TV) * 4) V4 { TV a[4]; };
 struct alignas(8) C4 { uint16_t c[4]; };
-struct alignas(16) W4 { uint32_t w[4]; };
+template <class WTy> struct alignas(sizeof(WTy) * 4) WQ { WTy w[4]; };   // the weights of a quad: 4, 8 or 16 bytes
+__global__ void k_max_u32(const uint32_t *__restrict__ a, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = a[i] > m ? a[i] : m;
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_down(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
 
-template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
+template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols,
-                                                           const C4 *__restrict__ LCOL4, const W4 *__restrict__ WT4,
+                                                           const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
                                                            const uint32_t *__restrict__ launch_order, uint32_t chunk0) {
@@ -437,15 +443,15 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
     // Software pipeline: the loads of trip t+1 are issued BEFORE the stores of trip t, so a wave does not wait
     // on its own store acknowledgements (vmcnt retires in order).
-    C4 lc[U], nlc[U]; uint32_t gw[U], ngw[U]; W4 w[U], nw[U];
-    auto issue_loads = [&](uint32_t g0, C4 (&olc)[U], uint32_t (&ogw)[U], W4 (&ow)[U]) {
+    C4 lc[U], nlc[U]; uint32_t gw[U], ngw[U]; WQ<WTy> w[U], nw[U];
+    auto issue_loads = [&](uint32_t g0, C4 (&olc)[U], uint32_t (&ogw)[U], WQ<WTy> (&ow)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
             const uint32_t q = g * 64 + lane;
             olc[u] = LCOL4[q];                                    // 8 B/lane
             ogw[u] = Gw[(uint64_t)g * 8 + (lane & 7)];            // lane i holds dword i & 7 of the 32-byte group record
-            if constexpr (WEIGHTED) ow[u] = WT4[q]; else ow[u] = W4{{0, 0, 0, 0}};
+            if constexpr (WEIGHTED) ow[u] = WT4[q]; else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
         }
     };
     uint32_t g0 = (q0c >> 6) + wave * U;
@@ -614,7 +620,9 @@ struct gt_pb {
     uint32_t nout = 0;         // padded outputs of the k-order (multiple of 4): slots of VAL / LROW
     uint32_t *cv0 = nullptr, *cv1 = nullptr, *ccol0 = nullptr;
     uint16_t *LCOL = nullptr, *LROW = nullptr;
-    uint32_t *WT = nullptr, *KSTART = nullptr;
+    void *WT = nullptr;        // weights of the v-order, wt_bytes (1, 2 or 4) each
+    int wt_bytes = 4;
+    uint32_t *KSTART = nullptr;
     void *G = nullptr;         // GroupRec per 256 padded entries
     BinWork *work = nullptr;
     std::vector<uint32_t> slice_chunk;   // chunks of slice k of the message vector: [slice_chunk[k], slice_chunk[k+1])
@@ -833,10 +841,16 @@ int gt_pb_build(gt_graph *g) {
     PB_MALLOC(pb->KSTART, (uint64_t)(nrun + 64) * 4);
     k_fill_t<uint16_t><<<grid_for(np), TPB, 0, s>>>(pb->LCOL, np, PADCOL);
     PB_HIP(hipMemsetAsync(pb->LROW, 0, (uint64_t)std::max(nout, 4u) * 2, s));
-    if (g->A) { PB_MALLOC(pb->WT, (uint64_t)np * 4); PB_HIP(hipMemsetAsync(pb->WT, 0, (uint64_t)np * 4, s)); }
+    if (g->A) {   // weights travel in the narrowest type that holds the largest one (the reference's converter draws 1..128)
+        DevBuf mx; PB_ALLOC(mx, 4); PB_HIP(hipMemsetAsync(mx.p, 0, 4, s));
+        k_max_u32<<<grid_for(nnz), TPB, 0, s>>>(g->A, nnz, mx.as<uint32_t>());
+        uint32_t wmax = 0; PB_HIP(hipMemcpy(&wmax, mx.p, 4, hipMemcpyDeviceToHost));
+        pb->wt_bytes = wmax < 256 ? 1 : wmax < 65536 ? 2 : 4;
+        PB_MALLOC(pb->WT, (uint64_t)np * pb->wt_bytes); PB_HIP(hipMemsetAsync(pb->WT, 0, (uint64_t)np * pb->wt_bytes, s));
+    }
     k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey64, sidx, sid, nnz, binbits, pb->ccol0, g->JI, g->A, vstart.as<uint32_t>(),
                                                    pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Eb.as<uint32_t>(), Xb.as<uint32_t>(),
-                                                   pb->LCOL, pb->LROW, pb->WT);
+                                                   pb->LCOL, pb->LROW, pb->WT, pb->wt_bytes);
     k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
     PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nrun + 64) * 4, s));
     k_kstart<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, pb->KSTART);
@@ -908,7 +922,7 @@ int gt_pb_build(gt_graph *g) {
     return GT_OK;
 }
 
-template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN>
+template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy = uint32_t>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
                   uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see k_pb_scatter).
@@ -924,8 +938,8 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     if (phases & GT_PB_PHASE1) {
         const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
         if (c1 > c0)
-            k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN><<<c1 - c0, P1_THREADS, 0, s>>>(
-                pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, (const C4 *)pb->LCOL, (const W4 *)pb->WT, pb->KSTART,
+            k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
+                pb->cv0, pb->cv1, pb->ccol0, g->ncols_total, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
                 (const GroupRec *)pb->G, x, (TV *)pb->VAL, filter ? pb->chunk_active : nullptr, pb->launch_order, c0);
     }
     if (phases & GT_PB_PHASE2) {
@@ -978,7 +992,9 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
         case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
+            if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
+            if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

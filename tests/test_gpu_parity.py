@@ -635,6 +635,18 @@ def test_adversarial_shapes_against_oracle(gt, O, shape):
     assert (r["distance"] == ref["distance"]).all() and r["iterations"] == ref["iterations"]
 
 
+@pytest.mark.parametrize("wmax", [200, 300, 70000])
+def test_sssp_weight_widths(gt, O, wmax):
+    """The weight stream of min-plus travels as u8, u16 or u32 depending on the largest weight: all three against the oracle"""
+    from graphtap_amd.rmat import rmat_edges
+    rng = np.random.RandomState(wmax)
+    e = rmat_edges(15, 8, 11)
+    w = np.concatenate([e, rng.randint(1, wmax + 1, size=(len(e), 1)).astype(np.uint32)], axis=1)
+    w[0, 2] = wmax                                    # the maximum is really there
+    ref = O.run_app("sssp", w, 1 << 15, root=1); r = run_min(gt, "sssp", w, 1 << 15, 1)
+    assert (r["distance"] == ref["distance"]).all() and r["iterations"] == ref["iterations"]
+
+
 def test_bfs_cc_sssp_properties_at_rmat20(gt):
     """Size-independent properties (R-MAT 20 symmetrised: ~32 M stored entries), checked on
     the host against the edge list itself: BFS parent/hops consistency (parent is a neighbour one level up, the
