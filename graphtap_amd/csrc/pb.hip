@@ -75,8 +75,11 @@ constexpr int P2_THREADS = 1024;
 #define GT_P2_U 2
 #endif
 constexpr int P2_U = GT_P2_U;            // quads in flight per lane in phase 2
-constexpr uint32_t AGG_MASK = 7;        // entries of the v-order that may share an output: 2 lanes x 4 (R-MAT-26: 1.40 entries per
-                                       // output with 4, 1.50 with 8, 1.56 with 16, 1.62 without a limit)
+#ifndef GT_AGG_LANES
+#define GT_AGG_LANES 2
+#endif
+constexpr int AGG_LANES = GT_AGG_LANES;             // lanes (quads) of phase 1 whose entries may share an output: R-MAT-26 has 1.40
+constexpr uint32_t AGG_MASK = 4 * AGG_LANES - 1;    // entries per output with 1, 1.50 with 2, 1.56 with 4, 1.62 without a limit
 constexpr uint16_t HEAD = 0x8000;
 constexpr uint16_t COLMASK = 0x3FFF;
 constexpr uint16_t GEND = 0x4000;      // last entry of its (quad, row) group
@@ -254,7 +257,7 @@ __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nru
     }
 }
 // E[pv] = 1 when the entry at padded v-position pv is the last of its (lane pair, row) group: a group is a maximal stretch of
-// one row inside one run and inside one aligned block of 8 entries (two lanes x four entries of phase 1)
+// one row inside one run and inside one aligned block of 4 * AGG_LANES entries (AGG_LANES lanes x four entries of phase 1)
 __global__ void k_group_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n,
                              const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart,
                              uint32_t *__restrict__ E) {
@@ -495,18 +498,31 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
                v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
-            // pairs of lanes: what the even lane's quad leaves open after its last group end (all of it when it has none)
-            // continues in the odd lane's first group -- one DPP hop, no LDS
+            // blocks of AGG_LANES lanes: what a lane's quad leaves open after its last group end (all of it when it has none)
+            // continues in the next lane's first group, possibly straight through lanes without a group end -- DPP
+            // row_shr:1 hops, no LDS
             TV tail = v3;
             bool open = !e2;
             tail = open ? comb(v2, tail) : tail; open = open && !e1;
             tail = open ? comb(v1, tail) : tail; open = open && !e0;
             tail = open ? comb(v0, tail) : tail;
-            const TV carry = dpp_shr1<TV>(e3 ? (IS_MIN ? (TV)GT_INF : (TV)0) : tail);
+            const TV neutralv = IS_MIN ? (TV)GT_INF : (TV)0;
+            const bool has_end = e0 || e1 || e2 || e3;
+            // (every DPP move is executed by ALL lanes, then selected: a source lane that is masked off reads as 0)
+            const int prev_open = __builtin_amdgcn_update_dpp(0, e3 ? 0 : 1, 0x111, 0xf, 0xf, true);
+            const bool take = (lane & (AGG_LANES - 1)) != 0 && prev_open != 0;
+            TV flow = tail;   // what leaves this lane when its quad ends open
+#pragma unroll
+            for (int hop = 2; hop < AGG_LANES; hop++) {
+                const TV up = dpp_shr1<TV>(flow);
+                flow = has_end ? tail : comb(tail, take ? up : neutralv);
+            }
+            const TV flow_up = dpp_shr1<TV>(flow);
+            const TV carry = take ? flow_up : neutralv;
             SV *st = stage[wave];
             const uint32_t dump = 256 + lane;
             __builtin_amdgcn_wave_barrier();
-            TV acc = (lane & 1) ? comb(carry, v0) : v0;
+            TV acc = comb(carry, v0);
             uint32_t pos = pex;
             st[e0 ? pos : dump] = SV{acc, pos + delta};
             acc = e0 ? v1 : comb(acc, v1); pos += e0 ? 1u : 0u;
