@@ -21,7 +21,9 @@ region (inputs resident, like the reference's "Execute time" which excludes ingr
 
 GTEPS = stored entries x K / t / 1e9. roofline.achieved = algorithmic bytes of one
 SpMV launch / mean SpMV kernel duration measured with HIP events on the launch stream;
-B_alg = 4 nnz + 4 (nnzcols+1) + F nnzcols + F nnzrows  (BASELINE.md section 3), F = 8.
+B_alg = 4 nnz + 4 (nnzcols+1) + Fx nnzcols + 8 nnzrows (Fx = 4 with f32 messages, else 8): SpMV bytes only.
+The fused applicator's bytes are reported separately (`frac_with_apply`); `f64_messages` is the all-f64 run of the
+same graph; `measured_ceiling_GBps` is this box's streaming-copy rate.
 """
 import argparse
 import ctypes as C
@@ -123,6 +125,7 @@ def main():
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64", action="store_true", help="skip the second, all-f64 run whose numbers go into `f64_messages`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
     ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb_f32msg"),
                     help="SpMV implementation (gt_spmv_variant): propagation blocking (default), the same with f32 messages, or the edge-atomic baseline")
@@ -172,53 +175,60 @@ def main():
     V.execute(1)
     VR = gt.PR_Program(G, True, False, False, gt._ROW_)   # apps/pr.cpp:46-50
     VR.initialize(V)
-    V.free()
     barrier()
     t_ingress = time.perf_counter() - t_in0
 
-    h = VR._handle()
-    # ---- warmup, then exactly K timed steps
-    done = 0
-    if args.warmup:
-        VR.execute(done + args.warmup); done += args.warmup
-    _lib.check(L.gt_program_enable_timing(h, 1))
-    ms0, n0 = C.c_double(), C.c_uint32()
-    _lib.check(L.gt_program_timing(h, C.byref(ms0), C.byref(n0), 1))
-    barrier()
-    t0 = time.perf_counter()
-    VR.execute(done + args.steps); done += args.steps
-    barrier()
-    dt = time.perf_counter() - t0
-    if world == 1:
-        spmv_ms, launches = VR.stats.spmv_ms, VR.stats.spmv_launches
-    else:
-        a, b = C.c_double(), C.c_uint32()
-        _lib.check(L.gt_program_timing(h, C.byref(a), C.byref(b), 1))
-        spmv_ms, launches = a.value, b.value
-    assert launches == args.steps, (launches, args.steps)
+    def timed_run(VR):
+        """W untimed warm-up steps, a fresh initialize(V) (untimed), then ONE execute(K) -- so that the timed steps are
+        exactly the reference's `pr <file> <n> K` (its TCSC_CF `last iteration` rule fires once, at step K) and the
+        printed checksum is the one the reference prints for K iterations."""
+        h = VR._handle()
+        if args.warmup:
+            VR.execute(args.warmup)
+            VR.initialize(V)
+        _lib.check(L.gt_program_enable_timing(h, 1))
+        ms0, n0 = C.c_double(), C.c_uint32()
+        _lib.check(L.gt_program_timing(h, C.byref(ms0), C.byref(n0), 1))
+        barrier()
+        t0 = time.perf_counter()
+        VR.execute(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if not G.exchange:
+            spmv_ms, launches = VR.stats.spmv_ms, VR.stats.spmv_launches
+        else:
+            a, b = C.c_double(), C.c_uint32()
+            _lib.check(L.gt_program_timing(h, C.byref(a), C.byref(b), 1))
+            spmv_ms, launches = a.value, b.value
+        assert launches == args.steps, (launches, args.steps)
+        return dt, spmv_ms / launches, launches
+
+    dt, kernel_ms, launches = timed_run(VR)
 
     i = G.info
-    F = 8
-    # IA + JA + x + y of the tile-row (on several ranks x / JA span the ncols_local columns the tile-row reads)
+    # SURVEY 8d: B_alg = 4 nnz [IA] + 4 (nnzcols+1) [JA] + Fx nnzcols [x] + 8 nnzrows [y] of the tile-row (on several ranks x / JA
+    # span the ncols_local columns the tile-row reads); Fx = bytes of a message as this variant keeps it in HBM
     ncols = i.nnzcols if world == 1 else i.ncols_local
-    b_alg = 4 * i.nnz_local + 4 * (ncols + 1) + F * ncols + F * i.nnzrows
+
+    def b_spmv_of(variant):
+        fx = 4 if variant == "pb_f32msg" else 8
+        return 4 * i.nnz_local + 4 * (ncols + 1) + fx * ncols + 8 * i.nnzrows
+    b_spmv = b_spmv_of(args.spmv)
     # one rank: the SpMV launch pair also runs PageRank's applicator + next messenger for the rows of the bins one
     # phase-2 workgroup owns (DESIGN 4.2); its compulsory bytes per such row: rank read + write, changed flag, degree,
-    # row->column map, message = 8 + 8 + 1 + 4 + 4 + (4 | 8)
-    fused_rows = int(VR.stats.fused_apply_rows) if world == 1 else 0
+    # row->column map, message = 8 + 8 + 1 + 4 + 4 + (4 | 8). Reported beside the headline fraction, never inside it.
+    fused_rows = int(VR.stats.fused_apply_rows) if not G.exchange else 0
     b_fused = fused_rows * (25 + (4 if args.spmv == "pb_f32msg" else 8))
-    b_spmv = b_alg
-    b_alg += b_fused
-    kernel_ms = spmv_ms / launches
-    t = torch.tensor([dt, kernel_ms, float(b_alg)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    t = torch.tensor([dt, kernel_ms, float(b_spmv), float(b_fused)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, kernel_ms, b_alg = float(t[0]), float(t[1]), float(t[2])
+    dt, kernel_ms, b_spmv, b_fused = float(t[0]), float(t[1]), float(t[2]), float(t[3])
     nnz = G.nnz_global
     value = nnz * args.steps / dt / 1e9
-    achieved = b_alg / (kernel_ms * 1e-3) / 1e9     # GB/s of the slowest rank's SpMV launch
+    achieved = b_spmv / (kernel_ms * 1e-3) / 1e9     # GB/s of the slowest rank's SpMV launch, SpMV bytes only
 
     checksum = VR.checksum(out=None)
+    iterations_total = VR.iteration
     traffic = None
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/collect_pmc.py from rocprofv3 --pmc passes
     if os.path.exists(tp):
@@ -228,6 +238,34 @@ def main():
             traffic = rec.get(key, {}).get("hbm_bytes_per_launch") if args.spmv == "pb_f32msg" else None
         except Exception:
             traffic = None
+
+    # the all-f64 path beside it (the reference's fp is double, apps/deg.h:19): same graph, messages kept in f64
+    f64_rec = None
+    if world == 1 and args.spmv == "pb_f32msg" and not args.no_f64:
+        VR.free()
+        _lib.check(L.gt_graph_select_spmv(G._h, _lib.GT_SPMV_PB))
+        VR = gt.PR_Program(G, True, False, False, gt._ROW_)
+        VR.initialize(V)
+        dt2, kms2, _ = timed_run(VR)
+        f64_rec = {"spmv": "pb", "value": nnz * args.steps / dt2 / 1e9, "unit": "GTEPS", "ms_per_step": dt2 * 1e3 / args.steps, "kernel_ms": kms2,
+                   "algorithmic_bytes_spmv": float(b_spmv_of("pb")), "frac": b_spmv_of("pb") / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "value_checksum": VR.checksum(out=None)[0]}
+
+    # streaming-copy ceiling of THIS box, measured live (4.7-4.8 TB/s copy against the 8 TB/s spec)
+    ceiling = None
+    if world == 1:
+        VR.free(); V.free(); G.free()
+        n = 1 << 29
+        a = torch.empty(n, dtype=torch.float32, device="cuda"); b = torch.ones(n, dtype=torch.float32, device="cuda")
+        a.copy_(b); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            a.copy_(b)
+        e1.record(); torch.cuda.synchronize()
+        ceiling = 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
     out = {
         "metric": "PageRank GTEPS on RMAT-%d" % scale, "value": value, "unit": "GTEPS", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
@@ -235,22 +273,24 @@ def main():
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(i.nnzrows_global), "nnzcols": int(i.nnzcols_global),
                    "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if world > 1 else "single tile",
-                   "ingress_s": round(t_ingress, 3), "iterations_total": VR.iteration, "value_checksum": checksum[0], "reachable": checksum[1]},
-        "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter<double,double> + k_pb_gather<double,double> (one SpMV = this launch pair)",
-                                                  "pb_f32msg": "k_pb_scatter<double,float> + k_pb_gather<double,float> (one SpMV = this launch pair)",
+                   "ingress_s": round(t_ingress, 3), "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
+        "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter* + k_pb_gather<double,double> (one SpMV = this launch group)",
+                                                  "pb_f32msg": "k_pb_scatter* + k_pb_gather<double,float> (one SpMV = this launch group)",
                                                   "edge": "k_spmv_edge<GT_PLUS_F64>"}[args.spmv], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
-                     "algorithmic_bytes_spmv": float(b_spmv), "algorithmic_bytes_fused_apply": float(b_fused), "fused_apply_rows": fused_rows,
-                     "kernel_ms": kernel_ms, "launches": launches},
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
+                     "frac_with_apply": (b_spmv + b_fused) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "algorithmic_bytes_fused_apply": float(b_fused), "fused_apply_rows": fused_rows,
+                     "measured_ceiling_GBps": ceiling, "kernel_ms": kernel_ms, "launches": launches},
     }
+    if f64_rec is not None:
+        out["f64_messages"] = f64_rec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        VR.free(); G.free()   # give the HBM back before the host-side runs
         main_b, port_b = cpu_baseline(scale, args.seed)
         out["cpu_baseline"] = main_b
         if port_b is not None:
             out["cpu_baseline_port"] = port_b
-    VR.free(); G.free()
     if world > 1:
+        VR.free(); V.free(); G.free()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -39,6 +39,7 @@ struct gt_program {
     bool stationary = true;
     bool initialized = false;
     bool converged = false;
+    bool check_sticky = false;   // vp:412-413: check_for_convergence is set by execute(0) and never cleared
     uint32_t iteration = 0;
     int semiring = 0;
     hipStream_t stream = 0;
@@ -80,7 +81,8 @@ struct gt_program {
 
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
 // scatter_gather_stationary vp:688-708 / _nonstationary vp:711-758 over the owned segment's
-// non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs.
+// non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs. `JC` is the slot -> vertex map
+// of the message vector's layout (gt_x_vertex: JC itself, or XV under the hubs-first layout of pb.hip).
 __global__ void k_msg_deg(uint32_t *__restrict__ x, uint32_t nc) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) x[j] = 1u;  // deg.h:35-37
 }
@@ -88,7 +90,9 @@ template <class TX>
 __global__ void k_msg_pr(TX *__restrict__ x, const uint32_t *__restrict__ JC, uint32_t nc,
                          const uint32_t *__restrict__ deg, const double *__restrict__ rank) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
-        uint32_t v = JC[j], d = deg[v];
+        uint32_t v = JC[j];
+        if (v == 0xFFFFFFFFu) continue;              // unused slot of the hubs-first layout
+        uint32_t d = deg[v];
         x[j] = (TX)(d ? rank[v] / (double)d : 0.0);  // pr.h:31-33
     }
 }
@@ -96,6 +100,7 @@ __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__
                           const uint8_t *__restrict__ C, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
         uint32_t v = JC[j];
+        if (v == 0xFFFFFFFFu) continue;              // unused slot of the hubs-first layout: stays infinity()
         // bfs.h:52-54 (vid), sssp.h:44-46 (distance), cc.h:38-40 (label); inactive -> infinity() vp:749-750
         x[j] = C[v] ? (kind == GT_BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;
     }
@@ -108,6 +113,11 @@ __global__ void k_col_counts(const uint32_t *__restrict__ JA, uint32_t ncols, co
         const uint32_t o = loc2glob ? loc2glob[c] : c;
         if (o != 0xFFFFFFFFu) y[o] = JA[c + 1] - JA[c];
     }
+}
+// compressed-column order -> slot order of the message vector (gt_spmv under the hubs-first layout)
+template <class TX>
+__global__ void k_to_slots(const TX *__restrict__ x, const uint32_t *__restrict__ xslot, uint32_t nc, TX *__restrict__ out) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) out[xslot[c]] = x[c];
 }
 // messages of the owned columns -> send buffer, block (slice k, destination d) after block (ingest.hip: k_send_list)
 template <class TX>
@@ -301,7 +311,7 @@ int gt_rmat_generate(void *dev_out, int scale, uint64_t seed, int weighted, uint
 // ---- graph
 int gt_graph_free(gt_graph *g) {
     if (!g) return GT_OK;
-    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx};
+    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx, g->xslot, g->XV, g->R2X, g->x_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     gt_pb_free(g->pb);
     delete g;
@@ -325,6 +335,7 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     // contiguous ranges of a multiplicatively hashed INTERNAL id space (a bijection on the next power of
     // two; results are reported in original ids, see gt_graph_vertex_ids).
     g->nint = g->info.nrows;
+    { const char *fe = getenv("GRAPHTAP_FORCE_EXCHANGE"); g->force_exchange = fe != nullptr && atoi(fe) != 0; }
     if (nranks > 1) {
         uint32_t M = 1; while (M < g->info.nrows && M < 0x80000000u) M <<= 1;
         GT_REQUIRE(M >= g->info.nrows, GT_ERR_UNSUPPORTED, "more than 2^31 vertices on several ranks");
@@ -348,6 +359,8 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     if (st != GT_OK) { gt_graph_free(g); return st; }
     const char *env = getenv("GRAPHTAP_SPMV");
     g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : (env && strcmp(env, "pb_f32msg") == 0) ? GT_SPMV_PB_F32MSG : GT_SPMV_PB;
+    st = gt_layout_build(g);
+    if (st != GT_OK) { gt_graph_free(g); return st; }
     if (g->spmv_variant != GT_SPMV_EDGE) {
         st = gt_pb_build(g);
         if (st != GT_OK) { gt_graph_free(g); return st; }
@@ -395,6 +408,17 @@ int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan) {
 
 int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream) {
     GT_REQUIRE(g && x_dev && y_dev, GT_ERR_INVALID, "null argument");
+    if (g->xslot && g->info.nnzcols) {   // hubs-first layout: the kernels read x by slot; the ABI's x is in compressed-column order
+        const uint32_t w = (semiring == GT_PLUS_F64) ? 8 : 4;
+        gt_graph *gm = const_cast<gt_graph *>(g);
+        if (!gm->x_scratch) GT_HIP(hipMalloc(&gm->x_scratch, (uint64_t)g->x_len * 8));
+        hipStream_t s = (hipStream_t)hip_stream;
+        GT_HIP(hipMemsetAsync(gm->x_scratch, 0, (uint64_t)g->x_len * w, s));   // unused slots are never referenced by an entry
+        if (w == 8) k_to_slots<uint64_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint64_t *)x_dev, g->xslot, g->info.nnzcols, (uint64_t *)gm->x_scratch);
+        else k_to_slots<uint32_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)x_dev, g->xslot, g->info.nnzcols, (uint32_t *)gm->x_scratch);
+        GT_HIP(hipGetLastError());
+        x_dev = gm->x_scratch;
+    }
     return gt_launch_spmv(g, semiring, x_dev, y_dev, (hipStream_t)hip_stream);
 }
 
@@ -433,7 +457,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
         default: p->semiring = GT_MIN_U32; break;
     }
     const uint32_t H = g->info.tile_height;
-    p->x_elems = g->ncols_total;
+    p->x_elems = g->x_len;
     p->y_elems = (prm->order == GT_COL) ? (uint64_t)g->info.nranks * g->info.seg_stride : g->info.nnzrows;
     bool ok = hipMalloc((void **)&p->s0, (uint64_t)H * 4) == hipSuccess && hipMalloc((void **)&p->C, H) == hipSuccess &&
               hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_bytes) == hipSuccess &&
@@ -445,7 +469,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
         ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess && hipMalloc((void **)&p->rank_c, nr * 8) == hipSuccess &&
              hipMalloc((void **)&p->deg_c, nr * 4) == hipSuccess && hipMalloc((void **)&p->C_c, nr) == hipSuccess;
     }
-    if (ok && g->info.nranks > 1)
+    if (ok && gt_has_exchange(g))
         ok = hipMalloc(&p->xseg, std::max<uint64_t>(g->info.nnzcols, 1) * p->x_bytes) == hipSuccess &&
              hipMalloc(&p->send_own, std::max<uint64_t>(g->send_elems, 1) * p->x_bytes) == hipSuccess;
     if (!ok) { gt_program_free(p); gt_set_error("out of device memory for program state"); return GT_ERR_HIP; }
@@ -483,7 +507,7 @@ static int init_common(gt_program *p) {
     const uint32_t H = g->info.tile_height, base = g->info.rank * H;
     hipStream_t s = p->stream;
     static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
-    p->iteration = 0; p->converged = false; p->init_epoch = ++epoch_counter;
+    p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter;
     switch (p->prm.kind) {
         case GT_DEG:  // deg.h:31-34
             GT_HIP(hipMemsetAsync(p->s0, 0, (uint64_t)H * 4, s));
@@ -579,8 +603,9 @@ int gt_program_iteration(const gt_program *p, uint32_t *iteration) {
 int gt_program_scatter_gather(gt_program *p) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "scatter_gather before initialize");
     const gt_graph *g = p->g;
-    const uint32_t nc = g->info.nnzcols;
-    if (p->prm.order == GT_COL || nc == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
+    if (p->prm.order == GT_COL || g->info.nnzcols == 0) return GT_OK;  // Deg/_COL_: messages are the constant 1, folded into combine
+    const uint32_t nc = gt_x_owned(g);             // slots of the owned columns' messages
+    const uint32_t *xv = gt_x_vertex(g);           // slot -> local vertex
     hipStream_t s = p->stream;
     void *xm = p->xseg ? p->xseg : p->x;   // several ranks: the owned columns' messages, packed per destination below
     if (p->x_fresh) p->x_fresh = false;   // the fused PageRank apply already wrote them
@@ -588,12 +613,12 @@ int gt_program_scatter_gather(gt_program *p) {
         case GT_DEG: k_msg_deg<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, nc); break;
         case GT_PR: {
             int st = pr_sync_state(p); if (st != GT_OK) return st;
-            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)xm, g->JC, nc, p->s0, p->rank);
-            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)xm, g->JC, nc, p->s0, p->rank);
+            if (p->x_f32) k_msg_pr<float><<<grid_for(nc), TPB, 0, s>>>((float *)xm, xv, nc, p->s0, p->rank);
+            else k_msg_pr<double><<<grid_for(nc), TPB, 0, s>>>((double *)xm, xv, nc, p->s0, p->rank);
             break;
         }
         default:
-            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, g->JC, nc, p->C, p->s0,
+            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->C, p->s0,
                                                    g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
             break;
     }
@@ -611,7 +636,7 @@ static bool fused_epilogue(gt_program *p, gt_pr_epilogue *epi) {
     const gt_graph *g = p->g;
     if (!(p->fuse_armed && p->prm.kind == GT_PR && g->spmv_variant != GT_SPMV_EDGE && g->pb != nullptr)) return false;
     const bool cf = (p->prm.compression == GT_TCSC_CF);
-    *epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, g->R2C, p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
+    *epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, gt_row_slot(g), p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
                           cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr};
     return true;
 }
@@ -738,7 +763,9 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     const gt_graph *g = p->g;
     hipStream_t s = p->stream;
     const uint32_t nr = g->info.nnzrows, H = g->info.tile_height;
-    if (p->converged) { if (active) *active = 0; return GT_OK; }
+    // converged: apply_*() is skipped (vp:1616-1632) but the driver still counts the trip (vp:421), so a later
+    // execute(n) terminates
+    if (p->converged) { p->iteration++; p->fused = false; p->fuse_armed = false; if (active) *active = 0; return GT_OK; }
     unsigned long long *d_active = active ? p->d_active : nullptr;   // counted only when the caller wants it (converge mode)
     const bool fused = p->fused;   // phase 2 already applied the rows of its single-workgroup bins (and counted them)
     p->fused = false; p->fuse_armed = false;
@@ -759,10 +786,10 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
             void *xm = p->xseg ? p->xseg : p->x;   // next iteration's messages of the owned columns
             if (nr && p->x_f32)
-                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
+                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
             else if (nr)
-                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, g->R2C, nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
+                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
                                                                     p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
@@ -798,10 +825,11 @@ int gt_program_finish_converged(gt_program *p) {
 
 int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
-    GT_REQUIRE(p->g->info.nranks == 1, GT_ERR_STATE,
+    GT_REQUIRE(!gt_has_exchange(p->g), GT_ERR_STATE,
                "gt_program_execute runs single-rank graphs; multi-rank runs drive scatter_gather/combine/apply with an exchange of x between them");
     if (!p->initialized) { int st = init_common(p); if (st != GT_OK) return st; }  // vp:410-411
-    const bool check = (iters == 0);                                               // vp:412-413
+    if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
+    const bool check = p->check_sticky;
     hipStream_t s = p->stream;
     p->ev_used = 0; p->spmv_done = 0;
     GT_HIP(hipStreamSynchronize(s));

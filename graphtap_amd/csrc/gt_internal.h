@@ -56,14 +56,35 @@ struct gt_graph {
     // Balanced relabelling for multi-rank graphs (identity when nranks == 1): internal id = (vid * perm_a) & perm_mask,
     // vid = (internal * perm_ainv) & perm_mask. Segments are contiguous ranges of INTERNAL ids.
     uint32_t perm_a = 1, perm_ainv = 1, perm_mask = 0xFFFFFFFFu, nint = 0;  // nint = size of the internal id space
+    // Layout of the message vector x (pb.hip, gt_layout_build). Identity (x_len = ncols_total, xslot = null) on graphs with an
+    // exchange layout and under GRAPHTAP_PB_HUBS=0. Otherwise HUBS FIRST: the nhub columns of largest out-degree occupy the
+    // first ndw windows of GT_PB_WINDOW slots (degree descending), the other columns follow in ascending compressed order
+    // from slot ndw * GT_PB_WINDOW on, in windows of GT_PB_SPARSE_WINDOW slots. Same-row entries of the hub windows then
+    // pre-aggregate several times better (R-MAT-26: 1.67 -> 2.3+ entries per (window, row) pair, tools/layout_stats.py).
+    uint32_t x_len = 0;            // slots of x
+    uint32_t ndw = 0;              // dense (aggregating, GT_PB_WINDOW wide) windows; the rest are sparse windows
+    uint32_t *xslot = nullptr;     // [nnzcols] compressed column -> slot of x, or null = identity
+    uint32_t *XV = nullptr;        // [x_len]   slot -> local vertex (what JC is for the identity layout), ~0u for an unused slot
+    uint32_t *R2X = nullptr;       // [nnzrows] compressed row -> slot of the same vertex's column, ~0u if none (R2C through xslot)
+    void *x_scratch = nullptr;     // [x_len] x 8 B: gt_spmv's copy of a caller's compressed-order x in slot order
+    bool force_exchange = false;  // GRAPHTAP_FORCE_EXCHANGE: exchange layout on a single rank (rehearses the N-rank driver path)
     struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
     int spmv_variant = 1;        // gt_spmv_variant
 };
 
+// true when the message vector lives in the LOCAL column space filled by an exchange (several ranks, or forced)
+inline bool gt_has_exchange(const gt_graph *g) { return g->loc2glob != nullptr; }
+// messengers walk the slots of x: slot -> local vertex (~0u = unused slot), and the row -> slot map of PageRank's applicator
+inline const uint32_t *gt_x_vertex(const gt_graph *g) { return g->XV ? g->XV : g->JC; }
+inline uint32_t gt_x_owned(const gt_graph *g) { return g->XV ? g->x_len : g->info.nnzcols; }
+inline const uint32_t *gt_row_slot(const gt_graph *g) { return g->R2X ? g->R2X : g->R2C; }
+
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
-#define GT_PB_WINDOW 8192u   // columns per phase-1 window (pb.hip); slice widths are multiples of it
+#define GT_PB_WINDOW 8192u   // columns per DENSE phase-1 window (pb.hip); slice widths are multiples of it
+#define GT_PB_SPARSE_WINDOW 16384u   // columns per SPARSE phase-1 window (low-degree columns: nothing to pre-aggregate)
 
 // pb.hip
+int gt_layout_build(gt_graph *g);   // x layout (hubs first); before gt_pb_build and before any program exists
 int gt_pb_build(gt_graph *g);
 void gt_pb_free(struct gt_pb *pb);
 // slices [slice_lo, slice_hi) of phase 1; phase 2 runs when slice_hi == x_slices. `phases` = 0 does what the slice range
@@ -75,7 +96,7 @@ enum { GT_PB_PREPARE = 1u, GT_PB_PHASE1 = 2u, GT_PB_PHASE2 = 4u };
 // directly and y is never touched for them; the rows of split bins go through y and k_pr_apply_msg as before
 // (gt_pb_bin_single tells the two apart).
 struct gt_pr_epilogue {
-    double *rank_c; const uint32_t *deg_c; uint8_t *C_c; const uint32_t *R2C;
+    double *rank_c; const uint32_t *deg_c; uint8_t *C_c; const uint32_t *R2X;   // R2X: row -> slot of x (gt_row_slot), ~0u for a source row
     void *x; int x_f32;
     double alpha, tol; int cf, last;
     unsigned long long *d_active;

@@ -228,6 +228,10 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     const int slots = f.directed ? 1 : 2;
     const uint64_t cap = m * slots;
     hipStream_t s = 0;
+    // the exchange layout (local column space, send list, K slices): always on several ranks; on ONE rank only when
+    // asked for (GRAPHTAP_FORCE_EXCHANGE), so that the whole multi-rank driver path -- RCCL self-exchange included --
+    // runs on a one-GPU box
+    const bool multi = p > 1 || g->force_exchange;
 
     DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby;
     ING_ALLOC(keys, cap * 8); ING_ALLOC(keys2, cap * 8);
@@ -238,7 +242,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     ING_HIP(hipMemsetAsync(rowflag.p, 0, span + 1, s));
     ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
     ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
-    if (p > 1) {
+    if (multi) {
         ING_ALLOC(needme, span + 1); ING_ALLOC(needby, span + 1);
         ING_ALLOC(Sneed, (span + 1) * 4); ING_ALLOC(Sby, (span + 1) * 4);
         ING_HIP(hipMemsetAsync(needme.p, 0, span + 1, s));
@@ -249,7 +253,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
-                                             p > 1 ? needme.as<uint8_t>() : nullptr, p > 1 ? needby.as<uint8_t>() : nullptr,
+                                             multi ? needme.as<uint8_t>() : nullptr, multi ? needby.as<uint8_t>() : nullptr,
                                              counters.as<unsigned long long>());
     unsigned long long hc[3];
     ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
@@ -273,7 +277,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         ING_ALLOC(tmp, tb);
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, rin, Srow.as<uint32_t>(), span + 1, s));
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cin, Scol.as<uint32_t>(), span + 1, s));
-        if (p > 1) {
+        if (multi) {
             hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> nin(needme.as<const uint8_t>(), U8ToU32());
             hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> bin(needby.as<const uint8_t>(), U8ToU32());
             ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nin, Sneed.as<uint32_t>(), span + 1, s));
@@ -292,7 +296,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     // Several ranks: the exchange of an iteration is cut into K slices (slice of compressed column j = j / T) so that
     // the all-to-all of slice k+1 can overlap phase 1 of slice k.
     uint32_t K = 1;
-    if (p > 1) {
+    if (multi) {
         const char *e = getenv("GRAPHTAP_X_SLICES");
         // Slicing is not free (engine.hip, combine_impl: +0.025 ms per step at K = 2, +0.05 ms at K = 4 on a tile-row of 8)
         // and hides (K-1)/K of the exchange: worth four slices while a rank receives tens of MB over one to three xGMI
@@ -312,7 +316,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     g->send_counts.assign((size_t)K * p, 0); g->recv_counts.assign((size_t)K * p, 0);
     g->send_off.assign(K + 1, 0); g->recv_off.assign(K + 1, 0);
     DevBuf rtab_d;
-    if (p == 1) {
+    if (!multi) {
         g->ncols_total = seg_stride;
         g->recv_off[1] = seg_stride;
     } else {
@@ -378,8 +382,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     g->info.ncols_local = g->ncols_total;
     g->info.send_elems = (uint32_t)g->send_elems;
 
-    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), p > 1 ? Sneed.as<uint32_t>() : nullptr,
-                                                        p > 1 ? rtab_d.as<BlockTab>() : nullptr, H, T, p);
+    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), multi ? Sneed.as<uint32_t>() : nullptr,
+                                                        multi ? rtab_d.as<BlockTab>() : nullptr, H, T, p);
     // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
     // so that the first copy of a duplicate (row,col) carries its minimum weight. Invalid keys sink
     // to the end. Radix sort is stable.

@@ -36,6 +36,7 @@ __device__ __forceinline__ void combine_one(T *__restrict__ y, uint32_t r, T xv,
 template <int SR>
 __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ IA, const uint32_t *__restrict__ JI,
                                                    const uint32_t *__restrict__ A, uint64_t nnz,
+                                                   const uint32_t *__restrict__ xslot /* compressed column -> slot of x, or null */,
                                                    const typename SemiringT<SR>::T *__restrict__ x,
                                                    typename SemiringT<SR>::T *__restrict__ y) {
     using T = typename SemiringT<SR>::T;
@@ -47,6 +48,7 @@ __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ 
     const uint4 *A4 = reinterpret_cast<const uint4 *>(A);
     for (uint64_t v = tid; v < nvec; v += nthreads) {
         uint4 r = IA4[v], c = JI4[v];
+        if (xslot) c = make_uint4(xslot[c.x], xslot[c.y], xslot[c.z], xslot[c.w]);
         uint4 w = make_uint4(0, 0, 0, 0);
         if constexpr (SR == GT_MINPLUS_U32) w = A4[v];
         T x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ 
         combine_one<SR, T>(y, r.w, x3, w.w);
     }
     for (uint64_t e = (nvec << 2) + tid; e < nnz; e += nthreads)
-        combine_one<SR, T>(y, IA[e], x[JI[e]], (SR == GT_MINPLUS_U32) ? A[e] : 0u);
+        combine_one<SR, T>(y, IA[e], x[xslot ? xslot[JI[e]] : JI[e]], (SR == GT_MINPLUS_U32) ? A[e] : 0u);
 }
 
 }  // namespace
@@ -81,17 +83,17 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
     if (blocks > 256 * 16) blocks = 256 * 16;
     switch (semiring) {
         case GT_PLUS_F64:
-            k_spmv_edge<GT_PLUS_F64><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, (const double *)x, (double *)y);
+            k_spmv_edge<GT_PLUS_F64><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, g->xslot, (const double *)x, (double *)y);
             break;
         case GT_PLUS_U32:
-            k_spmv_edge<GT_PLUS_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, (const uint32_t *)x, (uint32_t *)y);
+            k_spmv_edge<GT_PLUS_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, g->xslot, (const uint32_t *)x, (uint32_t *)y);
             break;
         case GT_MIN_U32:
-            k_spmv_edge<GT_MIN_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, (const uint32_t *)x, (uint32_t *)y);
+            k_spmv_edge<GT_MIN_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, g->xslot, (const uint32_t *)x, (uint32_t *)y);
             break;
         case GT_MINPLUS_U32:
             GT_REQUIRE(g->A != nullptr, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph (the reference builds sssp with -DHAS_WEIGHT, Makefile:26-27)");
-            k_spmv_edge<GT_MINPLUS_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, (const uint32_t *)x, (uint32_t *)y);
+            k_spmv_edge<GT_MINPLUS_U32><<<(unsigned)blocks, TPB, 0, s>>>(g->IA, g->JI, g->A, nnz, g->xslot, (const uint32_t *)x, (uint32_t *)y);
             break;
         default:
             gt_set_error("unknown semiring %d", semiring);

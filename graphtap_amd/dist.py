@@ -71,11 +71,18 @@ def run(engine, iters, group=None):
 
     With K = engine.x_slices > 1 the K all-to-alls of an iteration are issued back to back (async_op) on RCCL's
     stream and the local SpMV is driven slice by slice: phase 1 of slice k runs while slices k+1.. are in flight."""
-    check = (iters == 0)
+    if iters == 0:
+        engine.check_sticky = True      # vp:412-413: check_for_convergence is never cleared once execute(0) ran
+    check = getattr(engine, "check_sticky", False)
     p = engine.nranks
     K = getattr(engine, "x_slices", 1)
     x = engine.x_tensor()               # the message vector the local SpMV reads
-    exchange = p > 1 and engine.needs_x_exchange
+    if x.is_cuda and getattr(engine, "stream", None) is not None and torch.cuda.current_stream().cuda_stream != engine.stream:
+        # work.wait() orders the CURRENT torch stream behind a collective; the engine enqueues on the stream it was given
+        raise RuntimeError("dist.run: torch's current stream is not the stream the engine launches on")
+    forced = getattr(engine, "force_exchange", False)   # one rank with the exchange layout: every collective runs, with itself
+    multi = p > 1 or forced
+    exchange = multi and engine.needs_x_exchange
     if exchange:
         send, plan = engine.send_tensor(), engine.exchange_plan()
         if not getattr(engine, "_plan_verified", False):
@@ -98,11 +105,11 @@ def run(engine, iters, group=None):
                 for s in range(K):
                     exchange_slice(x, send, plan, s, group)
             engine.combine()
-        if p > 1 and engine.column_accumulators:
+        if multi and engine.column_accumulators:
             all_reduce_sum(engine.y_tensor(), group=group)
         active = engine.apply(iters, check)
         if check:
-            if p > 1:
+            if multi:
                 t = torch.tensor([active], dtype=torch.int64, device=x.device)
                 all_reduce_sum(t, group=group)
                 active = int(t.item())

@@ -61,6 +61,7 @@ class Graph:
         self.flags = None
         self.compression_type = _TCSC_
         self.rank, self.nranks = 0, 1
+        self.exchange = False   # the message vector is filled by an exchange (several ranks, or GRAPHTAP_FORCE_EXCHANGE on one)
 
     # -- Graph::load (graph.hpp:105-148)
     def load(self, filepath, nrows, ncols, directed=True, transpose=False, self_loops=True, acyclic=False,
@@ -95,6 +96,7 @@ class Graph:
             rank, nranks = world()
         self.free()
         self.rank, self.nranks = rank, nranks
+        self.exchange = nranks > 1 or os.environ.get("GRAPHTAP_FORCE_EXCHANGE", "0") not in ("", "0")
         self.compression_type = compression_type
         self.flags = GraphFlags(int(directed), int(transpose), int(self_loops), int(acyclic), int(parallel_edges))
         h = C.c_void_p()

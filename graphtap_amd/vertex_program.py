@@ -39,9 +39,11 @@ class _HipEngine:
         i = prog.G.info
         self.rank, self.nranks, self.seg_stride = i.rank, i.nranks, i.seg_stride
         self.x_slices, self.slice_width = i.x_slices, i.slice_width
+        self.force_exchange = prog.G.exchange and i.nranks == 1
         self.column_accumulators = (prog.ordering_type == _COL_)
         self.needs_x_exchange = not self.column_accumulators
         self._x = self._y = self._send = None
+        self.stream = None          # the HIP stream the program launches on (set by Vertex_Program.execute)
 
     def _tensor(self, getter):
         import torch
@@ -71,7 +73,7 @@ class _HipEngine:
         """The message vector the local SpMV reads (receive side of the exchange on several ranks); the
         single-rank case views the engine's own buffer."""
         if self._x is None:
-            if self.nranks > 1:
+            if self.prog.G.exchange:
                 self._x = self._installed(lib().gt_program_x, lib().gt_program_set_x)
             else:
                 self._x = self._tensor(lib().gt_program_x)
@@ -169,6 +171,8 @@ class Vertex_Program:
         else:
             check(lib().gt_program_initialize_from(self._handle(), other._handle()))
         self._already_initialized = True
+        if getattr(self, "_engine", None) is not None:
+            self._engine.check_sticky = False
 
     # -- execute(num_iterations = 0), vp:408-441
     def execute(self, num_iterations=0):
@@ -176,7 +180,7 @@ class Vertex_Program:
         h = self._handle()
         if not self._already_initialized:
             self.initialize()
-        if self.G.nranks == 1:
+        if not self.G.exchange:
             st = ExecStats()
             check(lib().gt_program_execute(h, self.num_iterations, C.byref(st)))
             self.stats = st
@@ -187,6 +191,7 @@ class Vertex_Program:
             check(lib().gt_program_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if getattr(self, "_engine", None) is None:
                 self._engine = _HipEngine(self)
+            self._engine.stream = torch.cuda.current_stream().cuda_stream
             _, self.converged = gdist.run(self._engine, self.num_iterations)
         return self
 

@@ -1,0 +1,224 @@
+"""Full-size GPU parity: the BENCHED variant at the BENCHED sizes, and the real multi-rank driver under pytest.
+
+* BASELINE config 2 exactly: PageRank R-MAT-22, 20 iterations, f32 messages (`pb_f32msg`, bench.py's default) against
+  the CPU oracle at full size (<= 1e-6 relative, degrees exact).
+* The headline configuration (R-MAT-26): `pb_f32msg` against the all-f64 `pb` variant on the GPU (<= 1e-6 relative)
+  plus size-independent properties.
+* graphtap_amd.dist.run driving the HIP engine: 2 processes sharing GPU 0 over gloo, and in-process over RCCL
+  (backend "nccl", world size 1, forced exchange layout) -- all_to_all_single on device tensors, async_op + wait,
+  combine_slice, the fused applicator: the code an N-GPU run executes.
+* BASELINE config 5's declared stand-in shape (symmetrised power-law R-MAT, edge factor 36): CC properties at full size.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PR_RTOL = 1e-6   # BASELINE.json north_star: "within 1e-6 relative for PageRank ranks"
+
+
+@pytest.fixture(scope="module")
+def gt():
+    import graphtap_amd as gt
+    gt._lib.require_gpu()
+    gt._lib.check(gt._lib.lib().gt_set_device(0))
+    return gt
+
+
+def _device_rmat(gt, scale, seed, weighted=False, edge_factor=16):
+    L = gt._lib.lib()
+    m = edge_factor << scale
+    d = C.c_void_p()
+    gt._lib.check(L.gt_malloc(C.byref(d), m * (12 if weighted else 8)))
+    gt._lib.check(L.gt_rmat_generate(d, scale, seed, int(weighted), 0, m, None))
+    return d, m
+
+
+def _pagerank_on_device_edges(gt, scale, seed, iters, variant):
+    """apps/pr.cpp on the R-MAT stream generated in HBM (what bench.py times)."""
+    L = gt._lib.lib()
+    nv = 1 << scale
+    old = os.environ.get("GRAPHTAP_SPMV")
+    os.environ["GRAPHTAP_SPMV"] = variant
+    try:
+        d, m = _device_rmat(gt, scale, seed)
+        G = gt.Graph()
+        G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+        gt._lib.check(L.gt_free(d))
+    finally:
+        if old is None:
+            del os.environ["GRAPHTAP_SPMV"]
+        else:
+            os.environ["GRAPHTAP_SPMV"] = old
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V); V.free()
+    VR.execute(iters)
+    out = dict(VR.V, iterations=VR.iteration, checksum=VR.checksum(out=None), nnz=int(G.info.nnz_local))
+    t = G.tile_to_host()
+    out["IR"] = t["IR"]
+    VR.free(); G.free()
+    return out
+
+
+def test_config2_pagerank_rmat22_f32_messages_against_oracle_at_full_size(gt):
+    """BASELINE.json configs[1]: PageRank R-MAT scale 22 (67 M records), fp32 messages, 20 iterations, one MI355X;
+    the oracle (bit-identical to the reference at np = 1, tests/test_oracle_golden.py) runs the same 67 M records."""
+    from graphtap_amd.rmat import rmat_edges
+    from oracle import oracle as O
+    scale, nv = 22, 1 << 22
+    r = _pagerank_on_device_edges(gt, scale, 1, 20, "pb_f32msg")
+    e = rmat_edges(scale, 16, 1)            # bit-identical to the device generator (test_device_rmat_generator_matches_host)
+    ref = O.run_app("pr", e, nv, iters=20)
+    assert r["nnz"] == len(e) and r["iterations"] == 20
+    assert (r["degree"] == ref["degree"]).all()
+    rel = np.abs(r["rank"] - ref["rank"]) / ref["rank"]
+    print("config 2 (R-MAT-22, pb_f32msg, 20 it): max rel rank err vs oracle %.3g" % rel.max())
+    assert rel.max() < PR_RTOL
+    ref_cs = O.checksum_f64(ref["rank"], nv + 1)       # the reference's truncating `Value checksum` / `Reachable vertices`
+    assert abs(int(r["checksum"][0]) - int(ref_cs[0])) <= 1 and r["checksum"][1] == ref_cs[1]
+    ref["graph"].close()
+
+
+def test_headline_pagerank_rmat26_f32_messages_against_f64_messages(gt):
+    """The headline configuration (bench.py default: R-MAT-26, 2^30 records, pb_f32msg): ranks against the all-f64
+    `pb` variant of the same engine (which the smaller tests pin to the oracle) and size-independent properties."""
+    scale, iters = 26, 20
+    a = _pagerank_on_device_edges(gt, scale, 1, iters, "pb_f32msg")
+    assert a["nnz"] == 16 << scale and a["iterations"] == iters
+    rank, deg = a["rank"], a["degree"]
+    assert np.isfinite(rank).all() and rank.min() >= 0.15 - 1e-15
+    has_row = np.zeros(len(rank), bool); has_row[a["IR"]] = True
+    assert (rank[~has_row] == 0.15).all() and (deg[~has_row] == 0).all()      # SURVEY 8a traps 1, 2
+    assert int(deg.astype(np.int64).sum()) <= 16 << scale
+    b = _pagerank_on_device_edges(gt, scale, 1, iters, "pb")
+    assert (a["degree"] == b["degree"]).all()
+    rel = np.abs(a["rank"] - b["rank"]) / b["rank"]
+    print("headline (R-MAT-26, 20 it): pb_f32msg vs pb max rel rank diff %.3g; checksums %s %s" % (rel.max(), a["checksum"], b["checksum"]))
+    assert rel.max() < PR_RTOL
+    assert abs(int(a["checksum"][0]) - int(b["checksum"][0])) <= 1 and a["checksum"][1] == b["checksum"][1]
+
+
+def test_two_processes_one_gpu_drive_the_hip_engine_through_dist_run():
+    """graphtap_amd.dist.run + _HipEngine (device buffers, C ABI) on 2 ranks that share GPU 0 (gloo, host-staged
+    collectives: RCCL refuses two ranks on one device): PageRank, BFS, CC, SSSP against the 1-rank run."""
+    env = dict(os.environ, GRAPHTAP_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env.pop("GRAPHTAP_SPMV", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "tools", "rehearse_2rank.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "2-rank rehearsal ok" in r.stdout
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(gt):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29654")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slices,fuse", [(2, "1"), (4, "0"), (1, "1")])
+def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slices, fuse, monkeypatch):
+    """World size 1 over RCCL with the exchange layout forced on (GRAPHTAP_FORCE_EXCHANGE): dist.run issues the K
+    all_to_all_single calls on device tensors (async_op), waits per slice, drives gt_program_combine_slice on the
+    helper streams, the fused applicator and the torch-owned x / send buffers -- everything an N-GPU run executes
+    except a second peer. Results must equal the plain single-rank engine's (gt_program_execute)."""
+    from graphtap_amd.rmat import rmat_edges
+    scale, nv = 17, 1 << 17
+    w = rmat_edges(scale, 16, 11, weighted=True); e = np.ascontiguousarray(w[:, :2])
+
+    def apps(forced):
+        if forced:
+            monkeypatch.setenv("GRAPHTAP_FORCE_EXCHANGE", "1"); monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+            monkeypatch.setenv("GRAPHTAP_FUSE_APPLY", fuse)
+        else:
+            for k in ("GRAPHTAP_FORCE_EXCHANGE", "GRAPHTAP_X_SLICES", "GRAPHTAP_FUSE_APPLY"):
+                monkeypatch.delenv(k, raising=False)
+        out = {}
+        for variant in ("pb_f32msg", "pb"):
+            monkeypatch.setenv("GRAPHTAP_SPMV", variant)
+            G = gt.Graph(); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+            assert G.exchange == forced and (G.info.x_slices == slices if forced else True)
+            V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+            P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(20)
+            out["pr_" + variant] = (P.V, P.iteration, P.checksum(out=None))
+            P.initialize(V); P.execute()      # converge mode: the 1-integer all-reduce
+            out["prc_" + variant] = (P.V, P.iteration, P.checksum(out=None))
+            P.free(); V.free(); G.free()
+        monkeypatch.delenv("GRAPHTAP_SPMV")
+        G = gt.Graph(); G.load_edges(e, nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = 3; P.execute()
+        out["bfs"] = (P.V, P.iteration, P.checksum(out=None)); P.free(); G.free()
+        G = gt.Graph(); G.load_edges(e, nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+        out["cc"] = (P.V, P.iteration, P.checksum(out=None)); P.free(); G.free()
+        G = gt.Graph(weighted=True); G.load_edges(w, nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.SSSP_Program(G, False, True, False, gt._ROW_); P.root = 3; P.execute()
+        out["sssp"] = (P.V, P.iteration, P.checksum(out=None)); P.free(); G.free()
+        return out
+
+    got, ref = apps(True), apps(False)
+    for k in ref:
+        (gv, git, gcs), (rv, rit, rcs) = got[k], ref[k]
+        if k == "prc_pb_f32msg":
+            # converge mode with f32 messages: the two layouts (hubs-first x on the plain engine, needed-columns x under the
+            # exchange) round the messages' sums in different orders, and a rank change sitting at the 1e-5 tolerance may
+            # tip one iteration earlier or later; the ranks then differ by one (tiny) iteration
+            assert abs(git - rit) <= 1, (k, git, rit)
+            assert (np.abs(gv["rank"] - rv["rank"]) / rv["rank"]).max() < 1e-4
+            continue
+        assert git == rit, (k, git, rit)
+        for f in rv:
+            if rv[f].dtype == np.float64:
+                rel = np.abs(gv[f] - rv[f]) / rv[f]
+                assert rel.max() < PR_RTOL, (k, f, rel.max())
+            else:
+                assert (gv[f] == rv[f]).all(), (k, f)
+        assert gcs[1] == rcs[1] and abs(int(gcs[0]) - int(rcs[0])) <= (1 if k.startswith("pr") else 0), (k, gcs, rcs)
+
+
+def test_config5_standin_cc_on_symmetrised_powerlaw_graph(gt):
+    """BASELINE.json configs[4] is CC on Twitter-2010 (41.6 M vertices, 1.47 G edges, graphtap1.slurm:49); the file is
+    not on the box (no network), so the DECLARED stand-in is a symmetrised R-MAT with Twitter's edge
+    factor 36: (a,b,c,d) = (.57,.19,.19,.05), self loops kept, deduplicated (apps/cc.cpp:24-43). One scale down from
+    the benchmarked stand-in (scale 24: 16.8 M vertices, 604 M records, ~1.1 G stored entries) to keep the host-side
+    checks in seconds. Properties at full size: every edge joins equal labels, a label is the smallest vertex id of
+    its component (label <= id, label is its own label), the iteration count is stable run to run."""
+    L = gt._lib.lib()
+    scale, ef, nv = 24, 36, 1 << 24
+    d, m = _device_rmat(gt, scale, 1, edge_factor=ef)
+    G = gt.Graph(); G.load_device(d.value, m, nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    its, labs = [], []
+    for _ in range(2):
+        P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+        its.append(P.iteration); labs.append(P.V["label"].astype(np.int64)); cs = P.checksum(out=None); P.free()
+    G.free()
+    assert its[0] == its[1] and (labs[0] == labs[1]).all()
+    lab = labs[0]
+    ids = np.arange(nv + 1)
+    assert (lab[:nv + 1] <= ids).all() and (lab[lab[:nv + 1]] == lab[:nv + 1]).all()
+    # every edge record joins equal labels: checked in slices of the device-resident record stream
+    step = 1 << 26
+    for first in range(0, m, step):
+        cnt = min(step, m - first)
+        h = np.empty((cnt, 2), np.uint32)
+        gt._lib.check(L.gt_memcpy_d2h(h.ctypes.data_as(C.c_void_p), C.c_void_p(d.value + first * 8), cnt * 8))
+        assert (lab[h[:, 0]] == lab[h[:, 1]]).all()
+    gt._lib.check(L.gt_free(d))
+    # label = min id of the component: a component's label is a member (own label) and no smaller id carries it
+    comp_min = np.full(nv + 2, np.iinfo(np.int64).max); np.minimum.at(comp_min, lab[:nv + 1], ids)
+    assert (comp_min[lab[:nv + 1]] == lab[:nv + 1]).all()
+    print("config 5 stand-in: CC on symmetrised R-MAT-%d ef %d: %d iterations, %d components, checksum %s"
+          % (scale, ef, its[0], int((lab[:nv + 1] == ids).sum()), cs))

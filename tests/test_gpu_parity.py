@@ -726,6 +726,20 @@ def test_api_misuse_is_reported_not_fatal(gt):
         VR.execute(2)
     assert L.gt_graph_select_spmv(G._h, 7) != 0 and b"variant" in L.gt_last_error()
     VR.free(); V.free(); G.free()
+    # execute() to convergence followed by execute(N) terminates: the reference's check_for_convergence flag is sticky
+    # (vp:412-413) and every trip of its loop counts (vp:421), so the second call makes exactly one more (no-op) trip
+    G = gt.Graph(); G.load_edges(c["edges"], 256, 256, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+    it, lab = P.iteration, P.V["label"].copy()
+    P.execute(it + 50)
+    assert P.iteration == it + 1 and (P.V["label"] == lab).all()
+    P.free()
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    VR = gt.PR_Program(G, True, False, False, gt._ROW_); VR.initialize(V); VR.execute()
+    it, rk = VR.iteration, VR.V["rank"].copy()
+    VR.execute(it + 7)
+    assert VR.iteration == it + 1 and (VR.V["rank"] == rk).all()
+    VR.free(); V.free(); G.free()
 
 
 def test_multirank_tile_rows_are_balanced(gt):
