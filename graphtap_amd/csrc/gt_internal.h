@@ -80,7 +80,10 @@ inline uint32_t gt_x_owned(const gt_graph *g) { return g->XV ? g->x_len : g->inf
 inline const uint32_t *gt_row_slot(const gt_graph *g) { return g->R2X ? g->R2X : g->R2C; }
 
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
-#define GT_PB_WINDOW 8192u   // columns per DENSE phase-1 window (pb.hip); slice widths are multiples of it
+#ifndef GT_PB_WINDOW
+#define GT_PB_WINDOW 16383u   // columns per DENSE phase-1 window (pb.hip): LDS slot GT_PB_WINDOW holds the neutral message that pad
+                              // entries read, and a column offset (or the pad) must fit 14 bits; slice widths are multiples of it
+#endif
 #define GT_PB_SPARSE_WINDOW 16384u   // columns per SPARSE phase-1 window (low-degree columns: nothing to pre-aggregate)
 
 // pb.hip

@@ -8,7 +8,7 @@
 //            slots of the message vector x, whose messages are staged in LDS (coalesced load); for every entry, in
 //            (chunk, row-bin) order, the value x[col] (+ w) goes to the entry's slot of the row-bin-major value stream VAL.
 //            Two kinds of windows (x is laid out HUBS FIRST on a single rank, gt_layout_build):
-//              DENSE  windows (W = 8192 slots, the columns of largest out-degree): consecutive entries of the same row
+//              DENSE  windows (W = 16383 slots, the columns of largest out-degree): consecutive entries of the same row
 //                     are PRE-AGGREGATED (+ or min) over whole 256-entry groups before they leave the chip -- a lane
 //                     combines its quad in registers, lanes meet through LDS atomics on the wave's staging row -- and
 //                     the (value, slot) pairs of a group are stored as coalesced runs (k_pb_scatter);
@@ -53,7 +53,8 @@ namespace {
 
 constexpr int RB = GT_PB_ROW_BIN_BITS;  // log2 rows per bin
 constexpr uint32_t R = 1u << RB;       // 16384 rows: 128 KiB of f64 accumulators in LDS (+ one dummy row for pads)
-constexpr uint32_t W = GT_PB_WINDOW;   // 8192 slots per dense window: 32 KiB (4-byte messages) or 64 KiB (f64) of LDS
+constexpr uint32_t W = GT_PB_WINDOW;   // 16383 slots per dense window (+ the neutral slot): 64 KiB (4-byte messages) or 128 KiB (f64) of LDS
+static_assert(W <= 0x3FFF, "a dense column offset and the pad slot W must fit the 14 column bits of LCOL");
 constexpr uint32_t WS = GT_PB_SPARSE_WINDOW;   // 16384 slots per sparse window: 64 KiB (4-byte messages) or 128 KiB (f64)
 // Entries per chunk. A window is one chunk unless it holds more than `ch` entries; such windows are cut by row bin (k_win_plan),
 // which leaves their runs whole, so `ch` only sets the granularity of the launch. Small graphs: the grid must
@@ -792,7 +793,7 @@ int gt_layout_build(gt_graph *g) {
     // degree >= 100 hold 73 % of the entries and 4.3 entries per (window, row) pair; columns below ~20 entries sit in windows
     // with 1.0x entries per pair, where the aggregation machinery only costs (tools/layout_stats.py).
     const char *et = getenv("GRAPHTAP_PB_HUB_DEG");
-    const uint32_t thr = et ? (uint32_t)atoi(et) : 48u;
+    const uint32_t thr = et ? (uint32_t)atoi(et) : 24u;
     struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } deg, hubflag, tailflag, hubpos, tailpos, key, key2, col, col2, tmp;
     for (Buf *b : {&deg, &hubflag, &tailflag, &hubpos, &tailpos}) LAY_HIP(hipMalloc(&b->p, (uint64_t)(nc + 1) * 4));
     LAY_HIP(hipMemsetAsync(hubflag.p, 0, (uint64_t)(nc + 1) * 4, s));

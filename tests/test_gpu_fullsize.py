@@ -173,10 +173,11 @@ def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slic
     for k in ref:
         (gv, git, gcs), (rv, rit, rcs) = got[k], ref[k]
         if k == "prc_pb_f32msg":
-            # converge mode with f32 messages: the two layouts (hubs-first x on the plain engine, needed-columns x under the
-            # exchange) round the messages' sums in different orders, and a rank change sitting at the 1e-5 tolerance may
-            # tip one iteration earlier or later; the ranks then differ by one (tiny) iteration
-            assert abs(git - rit) <= 1, (k, git, rit)
+            # converge mode with f32 messages: a hub's rank (~1e4) carries ~1e-8 relative = ~1e-4 absolute rounding noise,
+            # ABOVE the reference's absolute tolerance of 1e-5 (pr.h:13), so when the last rows stop "changing" depends on
+            # the order the two layouts (hubs-first x on the plain engine, needed-columns x under the exchange) add in: the
+            # iteration count may differ by a few, the ranks by a few (tiny) iterations. The all-f64 variant below is exact.
+            assert abs(git - rit) <= 5, (k, git, rit)
             assert (np.abs(gv["rank"] - rv["rank"]) / rv["rank"]).max() < 1e-4
             continue
         assert git == rit, (k, git, rit)
