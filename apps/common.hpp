@@ -11,11 +11,16 @@
 struct EndToEnd {
     const char *name;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    explicit EndToEnd(const char *n) : name(n) {}
-    ~EndToEnd() { printf("%s end-to-end time: %f seconds\n", name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    // Env::init() first, like the reference's mains (src/apps/pr.cpp:16): with GRAPHTAP_NGPUS=N this call forks the N rank
+    // processes before anything touches the GPU
+    explicit EndToEnd(const char *n) : name(n) { gt::Env::init(); t0 = std::chrono::steady_clock::now(); }
+    ~EndToEnd() {
+        GT_MASTER_PRINTF("%s end-to-end time: %f seconds\n", name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        try { gt::Env::finalize(); } catch (...) {}
+    }
 };
 
 static inline int usage(const char *argv0, const char *args) {
-    printf("\"Usage: %s %s\"\n", argv0, args);
+    GT_MASTER_PRINTF("\"Usage: %s %s\"\n", argv0, args);
     return 1;
 }

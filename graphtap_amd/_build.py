@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgraphtap_amd.so")
-SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip"]
+SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip", "dist.hip"]
 
 
 def _stale():
@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

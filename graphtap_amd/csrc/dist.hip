@@ -1,0 +1,333 @@
+// dist.hip -- the iteration loop over SEVERAL ranks (one process per GPU), host code in C++ calling RCCL directly.
+//
+// Replaces the communication the reference runs inside Vertex_Program::execute (src/vp/vertex_program.hpp:408-441) from its
+// C++ mains (src/apps/pr.cpp:15-60):
+//   MPI_Ibcast of every x segment down its column group, vp:843-862 / 970-1013  ->  K grouped ncclSend/ncclRecv rounds of the
+//       NEEDED columns only (gt_graph_exchange_plan), on a communication stream, slice k+1 in flight while the SpMV's
+//       phase 1 of slice k runs (gt_program_combine_slice, helper streams of engine.hip);
+//   Isend/Irecv of partial y to the row-group leader, vp:1083-1111              ->  gone: tile-rows make y complete locally;
+//                                                                                  Degree in _COL_ order: one ncclAllReduce;
+//   MPI_Allreduce of the convergence count, vp:1918, and of the checksums, vp:1940,1956 -> ncclAllReduce of 8-byte words.
+// graphtap_amd/dist.py is the same loop over torch.distributed (tests, bench.py); both drive the phase-level C ABI.
+//
+// Transports: RCCL (the product; librccl is resolved with dlopen so that a process that already carries a copy -- PyTorch
+// ships one -- keeps using that one, and a box without it still loads this library), and LOOPBACK: the p ranks of one process
+// on one GPU, one host thread each, exchanging with device copies -- the p-rank rehearsal a one-GPU box allows (RCCL refuses
+// two ranks on one device), used by tests/.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "gt_internal.h"
+
+namespace {
+
+// ---- RCCL entry points, resolved at first use
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);   // the copy this process already uses, if any
+            if (r.lib) break;
+        }
+        for (const char *name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!r.lib) return;
+#define GT_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
+        GT_SYM(GetUniqueId, "ncclGetUniqueId"); GT_SYM(CommInitRank, "ncclCommInitRank"); GT_SYM(CommDestroy, "ncclCommDestroy");
+        GT_SYM(GroupStart, "ncclGroupStart"); GT_SYM(GroupEnd, "ncclGroupEnd"); GT_SYM(Send, "ncclSend"); GT_SYM(Recv, "ncclRecv");
+        GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GetErrorString, "ncclGetErrorString");
+#undef GT_SYM
+        if (!(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce && r.GetErrorString)) r.lib = nullptr;
+    });
+    return r.lib ? &r : nullptr;
+}
+#define GT_NCCL(call)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess) { gt_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, rccl()->GetErrorString(r_)); return GT_ERR_HIP; } \
+    } while (0)
+
+__global__ void k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+// ---- loopback: what the p ranks of one process share
+struct LoopPeer { const char *send = nullptr; const uint32_t *y = nullptr; const gt_graph *g = nullptr; uint32_t x_bytes = 0; uint64_t word = 0; };
+struct LoopCtx {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<LoopPeer> peer;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+}  // namespace
+
+struct gt_dist {
+    int rank = 0, nranks = 1;
+    // RCCL
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr;
+    std::vector<hipEvent_t> ev_slice;
+    uint64_t *d_word = nullptr;     // device staging of the small all-reduces
+    // loopback
+    std::shared_ptr<LoopCtx> loop;
+    uint32_t *tmp = nullptr; uint64_t tmp_elems = 0;
+};
+
+namespace {
+
+int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s) {
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        for (uint32_t i = 0; i < count; i++) {     // one word at a time: this is test plumbing
+            c.peer[d->rank].word = v[i];
+            c.barrier();
+            uint64_t sum = 0;
+            for (int r = 0; r < c.n; r++) sum += c.peer[r].word;
+            c.barrier();
+            v[i] = sum;
+        }
+        return GT_OK;
+    }
+    GT_REQUIRE(count <= 64, GT_ERR_INVALID, "at most 64 words per all-reduce");
+    GT_HIP(hipMemcpyAsync(d->d_word, v, (size_t)count * 8, hipMemcpyHostToDevice, s));
+    GT_NCCL(rccl()->AllReduce(d->d_word, d->d_word, count, ncclUint64, ncclSum, d->comm, s));
+    GT_HIP(hipMemcpyAsync(v, d->d_word, (size_t)count * 8, hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    return GT_OK;
+}
+
+// the K slices of one iteration's exchange are ISSUED here (all of them); consume(k) then makes `s` wait for slice k
+int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
+    const gt_graph *g = p->g;
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, w = p->x_bytes;
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        GT_HIP(hipStreamSynchronize(s));                      // my send buffer is packed
+        c.barrier();
+        for (uint32_t k = 0; k < K; k++) {
+            uint64_t dst = g->recv_off[k];
+            for (uint32_t src = 0; src < P; src++) {
+                const gt_graph *gs = c.peer[src].g;
+                uint64_t off = gs->send_off[k];
+                for (uint32_t q = 0; q < (uint32_t)d->rank; q++) off += gs->send_counts[(size_t)k * P + q];
+                const uint32_t n = g->recv_counts[(size_t)k * P + src];
+                GT_REQUIRE(n == gs->send_counts[(size_t)k * P + d->rank], GT_ERR_STATE, "exchange plan mismatch between ranks %u and %d (slice %u)", src, d->rank, k);
+                if (n) GT_HIP(hipMemcpyAsync((char *)p->x + dst * w, c.peer[src].send + off * w, (uint64_t)n * w, hipMemcpyDeviceToDevice, s));
+                dst += n;
+            }
+        }
+        GT_HIP(hipStreamSynchronize(s));
+        c.barrier();                                          // every rank has read every send buffer
+        return GT_OK;
+    }
+    const ncclDataType_t ty = (w == 8) ? ncclUint64 : ncclUint32;
+    GT_HIP(hipEventRecord(d->ev_ready, s));
+    GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));   // sends read what scatter_gather packed; receives overwrite an x nobody reads any more
+    while (d->ev_slice.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_slice.push_back(e); }
+    for (uint32_t k = 0; k < K; k++) {
+        uint64_t so = g->send_off[k], ro = g->recv_off[k];
+        GT_NCCL(rccl()->GroupStart());
+        for (uint32_t q = 0; q < P; q++) {
+            const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
+            if (ns) GT_NCCL(rccl()->Send((const char *)p->send + so * w, ns, ty, (int)q, d->comm, d->comm_stream));
+            if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
+            so += ns; ro += nr;
+        }
+        GT_NCCL(rccl()->GroupEnd());
+        GT_HIP(hipEventRecord(d->ev_slice[k], d->comm_stream));
+    }
+    return GT_OK;
+}
+int exchange_consume(gt_dist *d, uint32_t k, hipStream_t s) {
+    if (!d->loop) GT_HIP(hipStreamWaitEvent(s, d->ev_slice[k], 0));
+    return GT_OK;
+}
+
+// Degree in _COL_ order: the column counts of all tile-rows are summed in the global column space
+int all_reduce_y(gt_dist *d, gt_program *p, hipStream_t s) {
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        if (d->tmp_elems < p->y_elems) {
+            if (d->tmp) GT_HIP(hipFree(d->tmp));
+            d->tmp = nullptr; d->tmp_elems = 0;
+            GT_HIP(hipMalloc((void **)&d->tmp, std::max<uint64_t>(p->y_elems, 1) * 4));
+            d->tmp_elems = p->y_elems;
+        }
+        GT_HIP(hipStreamSynchronize(s));
+        c.peer[d->rank].y = (const uint32_t *)p->y;
+        c.barrier();
+        GT_HIP(hipMemsetAsync(d->tmp, 0, p->y_elems * 4, s));
+        for (int r = 0; r < c.n; r++) k_add_u32<<<1024, 256, 0, s>>>(d->tmp, c.peer[r].y, p->y_elems);
+        GT_HIP(hipStreamSynchronize(s));
+        c.barrier();                                          // everybody has read everybody's partial counts
+        GT_HIP(hipMemcpyAsync(p->y, d->tmp, p->y_elems * 4, hipMemcpyDeviceToDevice, s));
+        return GT_OK;
+    }
+    GT_NCCL(rccl()->AllReduce(p->y, p->y, p->y_elems, ncclUint32, ncclSum, d->comm, s));
+    return GT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gt_dist_unique_id(void *id_out) {
+    GT_REQUIRE(id_out, GT_ERR_INVALID, "null argument");
+    GT_REQUIRE(rccl(), GT_ERR_UNSUPPORTED, "librccl could not be loaded");
+    ncclUniqueId id;
+    GT_NCCL(rccl()->GetUniqueId(&id));
+    static_assert(sizeof(id) == GT_DIST_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return GT_OK;
+}
+
+static int dist_init_common(gt_dist *d) {
+    GT_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+    GT_HIP(hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming));
+    GT_HIP(hipMalloc((void **)&d->d_word, 64 * 8));
+    return GT_OK;
+}
+
+int gt_dist_create(gt_dist **out, const void *unique_id, int rank, int nranks) {
+    GT_REQUIRE(out && unique_id && nranks >= 1 && rank >= 0 && rank < nranks, GT_ERR_INVALID, "gt_dist_create: bad arguments");
+    GT_REQUIRE(rccl(), GT_ERR_UNSUPPORTED, "librccl could not be loaded");
+    *out = nullptr;
+    gt_dist *d = new gt_dist();
+    d->rank = rank; d->nranks = nranks;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = rccl()->CommInitRank(&d->comm, nranks, id, rank);
+    if (r != ncclSuccess) { gt_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, rccl()->GetErrorString(r)); delete d; return GT_ERR_HIP; }
+    d->own_comm = true;
+    int st = dist_init_common(d);
+    if (st != GT_OK) { gt_dist_free(d); return st; }
+    *out = d;
+    return GT_OK;
+}
+
+int gt_dist_create_from_comm(gt_dist **out, void *nccl_comm, int rank, int nranks) {
+    GT_REQUIRE(out && nccl_comm && nranks >= 1 && rank >= 0 && rank < nranks, GT_ERR_INVALID, "gt_dist_create_from_comm: bad arguments");
+    GT_REQUIRE(rccl(), GT_ERR_UNSUPPORTED, "librccl could not be loaded");
+    *out = nullptr;
+    gt_dist *d = new gt_dist();
+    d->rank = rank; d->nranks = nranks; d->comm = (ncclComm_t)nccl_comm; d->own_comm = false;
+    int st = dist_init_common(d);
+    if (st != GT_OK) { gt_dist_free(d); return st; }
+    *out = d;
+    return GT_OK;
+}
+
+int gt_dist_create_loopback(gt_dist **out, int nranks) {
+    GT_REQUIRE(out && nranks >= 1, GT_ERR_INVALID, "gt_dist_create_loopback: bad arguments");
+    auto ctx = std::make_shared<LoopCtx>();
+    ctx->n = nranks; ctx->peer.resize(nranks);
+    for (int r = 0; r < nranks; r++) {
+        gt_dist *d = new gt_dist();
+        d->rank = r; d->nranks = nranks; d->loop = ctx;
+        out[r] = d;
+    }
+    return GT_OK;
+}
+
+int gt_dist_free(gt_dist *d) {
+    if (!d) return GT_OK;
+    if (d->comm && d->own_comm && rccl()) (void)rccl()->CommDestroy(d->comm);
+    if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+    for (hipEvent_t e : d->ev_slice) (void)hipEventDestroy(e);
+    if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
+    if (d->d_word) (void)hipFree(d->d_word);
+    if (d->tmp) (void)hipFree(d->tmp);
+    delete d;
+    return GT_OK;
+}
+
+int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count) {
+    GT_REQUIRE(d && host_values, GT_ERR_INVALID, "null argument");
+    return dist_all_reduce_words(d, host_values, count, d->comm_stream);
+}
+
+// Vertex_Program::execute (vp:408-441) over the ranks of `d`: every rank calls it with its own program of the same kind.
+int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats) {
+    GT_REQUIRE(d && p, GT_ERR_INVALID, "null argument");
+    const gt_graph *g = p->g;
+    GT_REQUIRE(gt_has_exchange(g), GT_ERR_STATE, "gt_dist_execute needs a graph built with the exchange layout (nranks > 1, or GRAPHTAP_FORCE_EXCHANGE)");
+    GT_REQUIRE((int)g->info.nranks == d->nranks && (int)g->info.rank == d->rank, GT_ERR_INVALID,
+               "graph is tile-row %u of %u, the communicator says rank %d of %d", g->info.rank, g->info.nranks, d->rank, d->nranks);
+    if (!p->initialized) { int st = gt_program_initialize(p); if (st != GT_OK) return st; }   // vp:410-411
+    if (iters == 0) p->check_sticky = true;                                                    // vp:412-413
+    const bool check = p->check_sticky;
+    const bool col = (p->prm.order == GT_COL);
+    const uint32_t K = g->info.x_slices;
+    hipStream_t s = p->stream;
+    if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
+    (void)gt_program_enable_timing(p, stats != nullptr);
+    p->ev_used = 0; p->spmv_done = 0;
+    GT_HIP(hipStreamSynchronize(s));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; }
+        if (!col && !p->converged) {
+            st = exchange_issue(d, p, s); if (st != GT_OK) return st;
+            for (uint32_t k = 0; k < K; k++) {
+                st = exchange_consume(d, k, s); if (st != GT_OK) return st;
+                st = (K > 1) ? gt_program_combine_slice(p, k) : gt_program_combine(p); if (st != GT_OK) return st;
+            }
+        } else {
+            st = gt_program_combine(p); if (st != GT_OK) return st;
+        }
+        if (col && !p->converged) { st = all_reduce_y(d, p, s); if (st != GT_OK) return st; }
+        uint64_t active = 0;
+        st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
+        if (check) {
+            st = dist_all_reduce_words(d, &active, 1, s); if (st != GT_OK) return st;       // has_converged, vp:1918
+            if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
+        } else if (p->iteration >= iters) break;
+    }
+    GT_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->iterations = p->iteration; stats->converged = p->converged;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double ms = 0; uint32_t n = 0;
+        (void)gt_program_timing(p, &ms, &n, 1);
+        stats->spmv_ms = ms; stats->spmv_launches = n;
+    }
+    return GT_OK;
+}
+
+}  // extern "C"

@@ -33,52 +33,6 @@ inline unsigned grid_for(uint64_t n) {
 }
 }  // namespace
 
-struct gt_program {
-    gt_graph *g = nullptr;
-    gt_program_params prm{};
-    bool stationary = true;
-    bool initialized = false;
-    bool converged = false;
-    bool check_sticky = false;   // vp:412-413: check_for_convergence is set by execute(0) and never cleared
-    uint32_t iteration = 0;
-    int semiring = 0;
-    hipStream_t stream = 0;
-    // V (vp:61) as struct-of-arrays over the owned segment, H entries each
-    uint32_t *s0 = nullptr;  // degree | parent | distance | label
-    uint32_t *s1 = nullptr;  // hops (BFS)
-    double *rank = nullptr;  // PageRank
-    uint8_t *C = nullptr;    // vp:161
-    // messages / accumulators (vp:159-160)
-    void *x_own = nullptr, *x = nullptr, *y = nullptr;
-    // several ranks: messages of the owned segment's columns [nnzcols] and their per-destination packing (ingest.hip)
-    void *xseg = nullptr, *send_own = nullptr, *send = nullptr;
-    uint64_t x_elems = 0, y_elems = 0;
-    uint32_t x_bytes = 4, y_bytes = 4;
-    unsigned long long *d_active = nullptr;
-    // PageRank working set in compressed-row space (dense, sequential): the V-space arrays above are
-    // brought up to date lazily (pr_sync_state) when somebody looks at V
-    double *rank_c = nullptr;   // [nnzrows]
-    uint32_t *deg_c = nullptr;  // [nnzrows]
-    uint8_t *C_c = nullptr;     // [nnzrows]
-    bool v_stale = false;       // compressed state is newer than V
-    bool x_fresh = false;       // the owned segment of x already holds the next iteration's messages
-    bool y_clean = false;       // y was zeroed by the fused apply
-    std::vector<hipEvent_t> ev;  // SpMV timing pairs
-    size_t ev_used = 0;
-    bool timing = false;
-    uint32_t spmv_done = 0;     // complete SpMVs among the timed event pairs (a sliced SpMV records one pair per slice)
-    uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
-    bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
-    // sliced combine (several ranks): phase 1 of slice k runs on helper stream k % size so that the tail of one slice
-    // overlaps the start of the next (and, in the pipelined driver, the exchange of the later slices)
-    // gt_program_execute: PageRank's apply of this iteration is fused into phase 2 for the row bins one workgroup owns
-    bool fuse_armed = false, fused = false;   // armed before combine; fused = the combine of this iteration did it
-    uint32_t fuse_iters = 0;
-    bool fuse_count = false;
-    std::vector<hipStream_t> slice_streams;
-    std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
-};
-
 // ------------------------------------------------------------------ messenger kernels (K7/K8)
 // scatter_gather_stationary vp:688-708 / _nonstationary vp:711-758 over the owned segment's
 // non-empty columns: x[j] = messenger(V[JC[j]]), C-gated to INF for the min programs. `JC` is the slot -> vertex map

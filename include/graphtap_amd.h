@@ -203,7 +203,7 @@ int gt_program_initialize(gt_program *p);
 /* initialize(other), vp:466-501: PageRank takes Deg's degrees where the row is non-empty */
 int gt_program_initialize_from(gt_program *p, const gt_program *other);
 /* execute(n), vp:408-441; iters == 0 runs until converged. Single-rank graphs only
- * (nranks == 1); multi-rank runs drive the three phases below with an exchange between them. */
+ * (nranks == 1); multi-rank runs go through gt_dist_execute (RCCL, below) or drive the three phases themselves. */
 int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats);
 /* Work of every later call on this handle is ordered on `hip_stream` (a hipStream_t). */
 int gt_program_set_stream(gt_program *p, void *hip_stream);
@@ -260,6 +260,31 @@ int gt_program_copy_state(gt_program *p, int field, void *host_out, uint64_t cou
 int gt_program_checksum(gt_program *p, uint64_t *value_sum, uint64_t *reachable);
 /* free(), vp:335-405 */
 int gt_program_free(gt_program *p);
+
+/* ---- several GPUs, one process (or, for rehearsal, one host thread) per rank: the iteration loop in C++ over RCCL ------
+ * Replaces the communication inside Vertex_Program::execute as driven by the reference's C++ mains
+ * (src/apps/pr.cpp:15-60): the MPI_Ibcast of x segments (vp:843-862, 970-1013) becomes K rounds of grouped
+ * ncclSend / ncclRecv of the NEEDED columns (gt_graph_exchange_plan) on a communication stream, slice k+1 in flight
+ * while phase 1 of slice k runs; the row-group reduce (vp:1083-1111) is gone (tile-rows make y complete locally; Degree
+ * in GT_COL order is one ncclAllReduce); has_converged (vp:1918) and the checksums (vp:1940,1956) are ncclAllReduce of
+ * 8-byte words. graphtap_amd/dist.py is the same loop over torch.distributed. */
+typedef struct gt_dist gt_dist;
+#define GT_DIST_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* rank 0: a fresh RCCL unique id, to be handed to every rank by the launcher (file, pipe, MPI_Bcast ...) */
+int gt_dist_unique_id(void *id_out);
+/* ncclCommInitRank on the calling thread's current device (gt_set_device first); collective over all ranks */
+int gt_dist_create(gt_dist **out, const void *unique_id, int rank, int nranks);
+/* the same over an ncclComm_t the caller already owns (it stays the caller's) */
+int gt_dist_create_from_comm(gt_dist **out, void *nccl_comm, int rank, int nranks);
+/* rehearsal transport: the nranks ranks of ONE process on ONE GPU (RCCL refuses two ranks on one device); out[nranks]
+ * handles, one per rank; every rank's gt_dist_execute must run on its own host thread */
+int gt_dist_create_loopback(gt_dist **out, int nranks);
+int gt_dist_free(gt_dist *d);
+/* execute(n), vp:408-441, over all ranks: every rank calls it with its own program (same kind, graphs built from the
+ * same edge list with rank / nranks of this communicator). iters == 0 runs until converged. */
+int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats);
+/* sum over ranks of `count` (<= 64) host words, in place: checksum() (vp:1940, 1956), nnz_global, display() */
+int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count);
 
 /* ---- kernel-level seam: spmv_stationary / spmv_nonstationary -----------
  * (vp:1116-1327, 1438-1506) y = A (x) x over the handle's tile-row, device pointers.

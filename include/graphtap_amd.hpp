@@ -27,6 +27,10 @@
 #include <string>
 #include <vector>
 
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "graphtap_amd.h"
 
 namespace gt {
@@ -41,6 +45,92 @@ struct Error : std::runtime_error {
 inline void check(int status) {
     if (status != GT_OK) throw Error(std::string("graphtap_amd: ") + gt_last_error());
 }
+
+// Env, src/mpi/env.hpp:22-55, over RCCL instead of MPI: one PROCESS per GPU, rank r drives GPU r and owns tile-row r.
+//   GRAPHTAP_NGPUS=N   Env::init() itself is the launcher: BEFORE anything touches HIP it forks N rank processes (the caller
+//                      becomes a pure waiter and exits with the ranks' worst status), rank 0 draws the RCCL unique id and
+//                      hands it over through a shared page;
+//   RANK / WORLD_SIZE [/ LOCAL_RANK] + GRAPHTAP_UID_FILE   an outside launcher (mpirun, torchrun, slurm) started the ranks:
+//                      rank 0 writes the unique id to that (shared) path, the others wait for it;
+//   neither            one rank, the reference's `mpirun -np 1`.
+// Only the master prints (Env::is_master, env.hpp:57), like the reference.
+struct Env {
+    static int &rank() { static int v = 0; return v; }
+    static int &nranks() { static int v = 1; return v; }
+    static gt_dist *&dist() { static gt_dist *d = nullptr; return d; }
+    static bool is_master() { return rank() == 0; }
+    static bool exchange() { const char *e = getenv("GRAPHTAP_FORCE_EXCHANGE"); return nranks() > 1 || (e && atoi(e) != 0); }
+
+    static void init() {
+        const char *ng = getenv("GRAPHTAP_NGPUS"), *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK");
+        unsigned char id[GT_DIST_UNIQUE_ID_BYTES];
+        int local = 0;
+        if (ng && atoi(ng) >= 1) {
+            const int n = atoi(ng);
+            struct Page { volatile int ready; unsigned char id[GT_DIST_UNIQUE_ID_BYTES]; };
+            Page *pg = (Page *)mmap(nullptr, sizeof(Page), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+            if (pg == MAP_FAILED) throw Error("Env::init: mmap failed");
+            pg->ready = 0;
+            std::vector<pid_t> kids;
+            int me = -1;
+            fflush(stdout); fflush(stderr);
+            for (int r = 0; r < n; r++) {
+                pid_t c = fork();
+                if (c < 0) throw Error("Env::init: fork failed");
+                if (c == 0) { me = r; break; }
+                kids.push_back(c);
+            }
+            if (me < 0) {   // the launcher itself: never initialises the GPU
+                int worst = 0;
+                for (pid_t c : kids) { int st = 0; waitpid(c, &st, 0); const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st); if (code > worst) worst = code; }
+                _exit(worst);
+            }
+            rank() = me; nranks() = n; local = me;
+            if (getenv("GRAPHTAP_SHARE_GPU")) local = 0;
+            check(gt_set_device(local));
+            if (me == 0) { check(gt_dist_unique_id((void *)pg->id)); __sync_synchronize(); pg->ready = 1; }
+            else while (!pg->ready) usleep(1000);
+            __sync_synchronize();
+            memcpy(id, (const void *)pg->id, sizeof(id));
+        } else if (ws && rk && atoi(ws) >= 1) {
+            rank() = atoi(rk); nranks() = atoi(ws);
+            local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank();
+            check(gt_set_device(local));
+            const char *path = getenv("GRAPHTAP_UID_FILE");
+            if (!path) throw Error("Env::init: RANK/WORLD_SIZE are set but GRAPHTAP_UID_FILE (shared path for the RCCL unique id) is not");
+            if (rank() == 0) {
+                check(gt_dist_unique_id(id));
+                const std::string tmp = std::string(path) + ".tmp";
+                FILE *f = fopen(tmp.c_str(), "wb");
+                if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw Error("Env::init: cannot write GRAPHTAP_UID_FILE");
+                fclose(f);
+                if (rename(tmp.c_str(), path) != 0) throw Error("Env::init: cannot publish GRAPHTAP_UID_FILE");
+            } else {
+                for (int tries = 0;; tries++) {
+                    FILE *f = fopen(path, "rb");
+                    if (f) { const size_t got = fread(id, 1, sizeof(id), f); fclose(f); if (got == sizeof(id)) break; }
+                    if (tries > 60000) throw Error("Env::init: timed out waiting for GRAPHTAP_UID_FILE");
+                    usleep(1000);
+                }
+            }
+        } else {
+            if (!exchange()) return;            // plain single rank: no communicator at all
+            check(gt_set_device(0));
+            check(gt_dist_unique_id(id));       // one rank with the exchange layout forced on: RCCL with itself
+        }
+        check(gt_dist_create(&dist(), id, rank(), nranks()));
+    }
+    static void finalize() {
+        if (dist()) { check(gt_dist_free(dist())); dist() = nullptr; }
+        fflush(stdout);
+    }
+    // sum over ranks, in place (no-op on one rank without a communicator)
+    static void all_reduce(uint64_t *v, uint32_t count) {
+        if (!dist()) return;
+        for (uint32_t i = 0; i < count; i += 64) check(gt_dist_all_reduce_u64(dist(), v + i, count - i < 64 ? count - i : 64));
+    }
+};
+#define GT_MASTER_PRINTF(...) do { if (::gt::Env::is_master()) printf(__VA_ARGS__); } while (0)
 
 class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hpp:31-71
   public:
@@ -69,14 +159,14 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
         if (text) {
             std::vector<uint32_t> recs = parse_text(buf, weighted_ ? 3 : 2);
             const uint64_t m = recs.size() / (weighted_ ? 3 : 2);
-            printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
+            GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
             load_edges(recs.data(), m, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
         } else {
             if (bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
-            printf("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
+            GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
             load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
         }
-        printf("Ingress time: %f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        GT_MASTER_PRINTF("Ingress time: %f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     // ASCII edge list, parread_text (graph.hpp:195-304): leading '#' / '%' / empty lines are skipped, every other line is
     // "row col[ weight]" separated by single spaces (a different column count is "read() failure", :250-257), the list
@@ -113,15 +203,20 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
                     bool acyclic, bool parallel_edges, Compression_type compression_type, bool on_device = false) {
         free();
         gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
-        check(gt_graph_build(&h_, edges, m, on_device, weighted_, num_vertices, &f, 0, 1));
+        // every rank reads the whole edge list and keeps its tile-row (the reference's ranks read 1/p each and shuffle,
+        // matrix.hpp:693-810; here the device ingest filters)
+        check(gt_graph_build(&h_, edges, m, on_device, weighted_, num_vertices, &f, Env::rank(), Env::nranks()));
         check(gt_graph_info_get(h_, &info));
         compression = compression_type;
+        nnz_global = info.nnz_local;
+        Env::all_reduce(&nnz_global, 1);
     }
     void free() {
         if (h_) { check(gt_graph_free(h_)); h_ = nullptr; }
     }
     gt_graph *handle() const { return h_; }
     gt_graph_info info{};
+    uint64_t nnz_global = 0;
     Compression_type compression = _TCSC_;
 
   private:
@@ -141,21 +236,27 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
     void execute(uint32_t num_iterations_ = 0) {  // vp:408-441
         num_iterations = num_iterations_;
         if (!already_initialized_) initialize();
-        check(gt_program_execute(handle(), num_iterations, &stats));
+        if (Env::exchange()) {   // several ranks: the loop with the exchange of x over RCCL (csrc/dist.hip)
+            if (!Env::dist()) throw Error("several ranks need gt::Env::init() before the first program runs");
+            check(gt_dist_execute(Env::dist(), handle(), num_iterations, &stats));
+        } else check(gt_program_execute(handle(), num_iterations, &stats));
+        const uint32_t first = iteration + 1;
         iteration = stats.iterations;
-        for (uint32_t i = 1; i <= iteration; i++) printf("Iteration:  %u\n", i);  // vp:422
-        printf("Execute time: %f seconds\n", stats.seconds);                       // vp:437
+        for (uint32_t i = first; i <= iteration; i++) GT_MASTER_PRINTF("Iteration:  %u\n", i);  // vp:422
+        GT_MASTER_PRINTF("Execute time: %f seconds\n", stats.seconds);                          // vp:437
         if (getenv("GRAPHTAP_TIMING"))   // the reference's -DTIMING record, vp:2145-2152 (sums only: one call, no per-iteration std-dev)
-            printf("TIMING scatter_gather %f combine %f apply %f execute %f ms (SpMV kernels %f ms over %u launches)\n",
+            GT_MASTER_PRINTF("TIMING scatter_gather %f combine %f apply %f execute %f ms (SpMV kernels %f ms over %u launches)\n",
                    stats.scatter_gather_ms, stats.combine_ms, stats.apply_ms, stats.seconds * 1e3, stats.spmv_ms, stats.spmv_launches);
     }
     void checksum() {  // vp:1927-1960
-        uint64_t s = 0, c = 0;
-        check(gt_program_checksum(handle(), &s, &c));
-        printf("Iterations: %u\nValue checksum: %llu\nReachable vertices: %llu\n", iteration, (unsigned long long)s, (unsigned long long)c);
+        uint64_t sc[2] = {0, 0};
+        check(gt_program_checksum(handle(), &sc[0], &sc[1]));
+        Env::all_reduce(sc, 2);   // MPI_Allreduce, vp:1940, 1956
+        GT_MASTER_PRINTF("Iterations: %u\nValue checksum: %llu\nReachable vertices: %llu\n", iteration, (unsigned long long)sc[0], (unsigned long long)sc[1]);
     }
     // checksum1(), vp:1963-2119: statistics of an integer state (used by apps/deg.cpp on the degrees)
     void checksum1(int field) {
+        if (Env::nranks() > 1) throw Error("checksum1 is implemented for one rank");
         const uint32_t H = G_.info.tile_height, n = G_.info.nrows;
         std::vector<uint32_t> v = state_u32(field, H);
         uint64_t sum = 0; double sq = 0; uint32_t maxv = 0, maxi = 0;
@@ -171,9 +272,12 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
     }
     virtual std::string print_state(uint32_t i) = 0;
     void display(uint32_t count = 31) {  // vp:2124-2181
-        count = count < G_.info.tile_height ? count : G_.info.tile_height;
+        // the reference prints the first states of rank 0's segment = vertices 0..30 at np = 1; on several ranks the
+        // segments are ranges of a hashed id space, so the first `count` VERTICES are collected from their owners
+        const uint32_t limit = Env::nranks() > 1 ? G_.info.nrows : G_.info.tile_height;
+        count = count < limit ? count : limit;
         fetch(count);
-        for (uint32_t i = 0; i < count; i++) printf("vertex[%u]:%s\n", i, print_state(i).c_str());
+        for (uint32_t i = 0; i < count; i++) GT_MASTER_PRINTF("vertex[%u]:%s\n", i, print_state(i).c_str());
     }
     void free() {
         if (h_) { check(gt_program_free(h_)); h_ = nullptr; }
@@ -185,15 +289,29 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
         }
         return h_;
     }
+    // state of the first `count` vertices (on one rank: the first `count` slots, which are the same thing)
     std::vector<uint32_t> state_u32(int field, uint32_t count) {
+        if (Env::nranks() > 1) { std::vector<uint64_t> w = gathered(field, count, false); return std::vector<uint32_t>(w.begin(), w.end()); }
         std::vector<uint32_t> v(count);
         check(gt_program_copy_state(handle(), field, v.data(), count));
         return v;
     }
     std::vector<double> state_f64(int field, uint32_t count) {
         std::vector<double> v(count);
+        if (Env::nranks() > 1) { std::vector<uint64_t> w = gathered(field, count, true); memcpy(v.data(), w.data(), (size_t)count * 8); return v; }
         check(gt_program_copy_state(handle(), field, v.data(), count));
         return v;
+    }
+    // several ranks: every vertex below `count` is owned by exactly one rank; the others contribute 0 to a sum of words
+    std::vector<uint64_t> gathered(int field, uint32_t count, bool f64) {
+        const uint32_t H = G_.info.tile_height;
+        std::vector<uint32_t> vid(H);
+        check(gt_graph_vertex_ids(G_.handle(), vid.data(), H));
+        std::vector<uint64_t> w(count, 0);
+        if (f64) { std::vector<double> v(H); check(gt_program_copy_state(handle(), field, v.data(), H)); for (uint32_t i = 0; i < H; i++) if (vid[i] < count) memcpy(&w[vid[i]], &v[i], 8); }
+        else { std::vector<uint32_t> v(H); check(gt_program_copy_state(handle(), field, v.data(), H)); for (uint32_t i = 0; i < H; i++) if (vid[i] < count) w[vid[i]] = v[i]; }
+        Env::all_reduce(w.data(), count);
+        return w;
     }
 
     uint32_t num_iterations = 0, iteration = 0, root = 0;

@@ -1,0 +1,157 @@
+"""The C++ multi-rank driver (graphtap_amd/csrc/dist.hip: gt_dist_execute, host code in C++ calling RCCL directly).
+
+* p ranks of one process on one GPU over the LOOPBACK transport (one host thread per rank, device copies instead of
+  RCCL -- which refuses two ranks on one device): all five programs against the reference's golden vectors and
+  against the Python driver (graphtap_amd.dist.run).
+* the application mains under the built-in launcher: `GRAPHTAP_NGPUS=1 GRAPHTAP_FORCE_EXCHANGE=1 apps/bin/pr ...`
+  forks one rank process, which runs every grouped ncclSend/ncclRecv round and ncclAllReduce of an N-GPU run with
+  itself (world size 1 over RCCL); printed lines must equal the plain single-rank run's.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_case
+
+pytestmark = pytest.mark.gpu
+
+PR_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gt():
+    import graphtap_amd as gt
+    gt._lib.require_gpu()
+    gt._lib.check(gt._lib.lib().gt_set_device(0))
+    return gt
+
+
+def _dist_execute_all(gt, dists, progs, iters):
+    """gt_dist_execute of every rank on its own host thread (ctypes releases the GIL during the call)"""
+    L = gt._lib.lib()
+    out = [None] * len(progs)
+
+    def work(r):
+        st = gt._lib.ExecStats()
+        L.gt_set_device(0)
+        rc = L.gt_dist_execute(dists[r], progs[r]._handle(), iters, C.byref(st))
+        out[r] = (rc, L.gt_last_error().decode() if rc else "", st.iterations, st.converged)
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(len(progs))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for r, (rc, msg, _, _) in enumerate(out):
+        assert rc == 0, "rank %d: %s" % (r, msg)
+    assert len({o[2] for o in out}) == 1
+    for p in progs:
+        p._already_initialized = True
+    return out[0][2], bool(out[0][3])
+
+
+def _gather(progs, field, n):
+    out = np.zeros(n, progs[0].V[field].dtype); seen = np.zeros(n, bool)
+    for p in progs:
+        vids = p.G.vertex_ids(); keep = vids != 0xFFFFFFFF
+        out[vids[keep]] = p.V[field][keep]; assert not seen[vids[keep]].any(); seen[vids[keep]] = True
+    assert seen.all()
+    return out
+
+
+@pytest.mark.parametrize("nranks,slices,variant", [(2, 4, "pb"), (3, 2, "pb_f32msg"), (8, 1, "pb"), (4, 2, "edge")])
+@pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
+def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, slices, variant, monkeypatch, known_answers):
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_SPMV", variant)
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    hs = (C.c_void_p * nranks)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, nranks))
+    dists = [C.c_void_p(hs[r]) for r in range(nranks)]
+    try:
+        # apps/pr.cpp: Deg in _COL_ order (all-reduce of the column counts), then PageRank, fixed count and converge mode
+        Gs = []
+        for r in range(nranks):
+            G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=r, nranks=nranks); Gs.append(G)
+        degs = [gt.Deg_Program(G, True, False, False, gt._COL_) for G in Gs]
+        for p in degs: p.initialize()
+        it, _ = _dist_execute_all(gt, dists, degs, 1)
+        assert it == 1
+        prs = [gt.PR_Program(G, True, False, False, gt._ROW_) for G in Gs]
+        for p, d in zip(prs, degs): p.initialize(d)
+        it, conv = _dist_execute_all(gt, dists, prs, 20)
+        assert it == 20 and not conv
+        assert (_gather(prs, "degree", n) == c["np1_pr20_a"]).all()
+        ref = c["np1_pr20_c"]
+        assert (np.abs(_gather(prs, "rank", n) - ref) / ref).max() < PR_RTOL
+        if variant != "pb_f32msg":   # converge mode: the f32-message variant's iteration count is rounding-noise dependent
+            for p, d in zip(prs, degs): p.initialize(d)
+            it, conv = _dist_execute_all(gt, dists, prs, 0)
+            assert conv and it == known_answers[name]["np1_prconv_cf"]["iterations"]
+            ref = c["np1_prconv_cf_c"]
+            assert (np.abs(_gather(prs, "rank", n) - ref) / ref).max() < PR_RTOL
+        for p in prs + degs: p.free()
+        for G in Gs: G.free()
+        # BFS
+        Gs = []
+        for r in range(nranks):
+            G = gt.Graph(); G.load_edges(c["edges"], nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
+        ps = [gt.BFS_Program(G, False, False, True, gt._ROW_) for G in Gs]
+        for p in ps: p.root = c["root"]; p.initialize()
+        it, conv = _dist_execute_all(gt, dists, ps, 0)
+        assert conv
+        assert (_gather(ps, "parent", n) == c["np1_bfs_a"]).all() and (_gather(ps, "hops", n) == c["np1_bfs_b"]).all()
+        for p in ps: p.free()
+        for G in Gs: G.free()
+        # CC (self loops kept)
+        Gs = []
+        for r in range(nranks):
+            G = gt.Graph(); G.load_edges(c["edges"], nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
+        ps = [gt.CC_Program(G, False, True, False, gt._ROW_) for G in Gs]
+        for p in ps: p.initialize()
+        _dist_execute_all(gt, dists, ps, 0)
+        assert (_gather(ps, "label", n) == c["np1_cc_a"]).all()
+        for p in ps: p.free()
+        for G in Gs: G.free()
+        # SSSP
+        Gs = []
+        for r in range(nranks):
+            G = gt.Graph(weighted=True); G.load_edges(c["wedges"], nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
+        ps = [gt.SSSP_Program(G, False, True, False, gt._ROW_) for G in Gs]
+        for p in ps: p.root = c["root"]; p.initialize()
+        _dist_execute_all(gt, dists, ps, 0)
+        assert (_gather(ps, "distance", n) == c["np1_sssp_a"]).all()
+        for p in ps: p.free()
+        for G in Gs: G.free()
+    finally:
+        for d in dists: L.gt_dist_free(d)
+
+
+def _app(app, args, env_extra):
+    exe = os.path.join(ROOT, "apps", "bin", app)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "apps"), "all"])
+    env = dict(os.environ, **env_extra)
+    for k in ("GRAPHTAP_SPMV",):
+        env.pop(k, None)
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    keep = ("Iterations:", "Value checksum:", "Reachable vertices:", "vertex[")
+    return [l for l in r.stdout.splitlines() if l.startswith(keep)]
+
+
+@pytest.mark.parametrize("slices", [1, 2, 4])
+def test_mains_under_the_rccl_launcher_print_the_single_rank_lines(slices):
+    """World size 1 over RCCL through the C++ host path: Env::init() forks the rank process before any HIP call, the rank
+    creates its communicator from the unique id, and gt_dist_execute runs the grouped send/recv rounds, the
+    ncclAllReduce of Degree's column counts and of the convergence count with itself."""
+    launch = {"GRAPHTAP_NGPUS": "1", "GRAPHTAP_FORCE_EXCHANGE": "1", "GRAPHTAP_X_SLICES": str(slices)}
+    f, fw = os.path.join(GOLDEN, "rmat10_1024.bin"), os.path.join(GOLDEN, "rmat10_1024_w.bin")
+    for app, args in (("pr", (f, 1024, 20)), ("pr", (f, 1024)), ("bfs", (f, 1024, 0)), ("cc", (f, 1024)), ("sssp", (fw, 1024, 0))):
+        plain = _app(app, args, {})
+        multi = _app(app, args, launch)
+        assert multi == plain and len(plain) >= 34, (app, args, plain[:4], multi[:4])
+    out = _app("pr", (f, 1024, 20), launch)
+    assert "Value checksum: 70" in out and "vertex[4]:Rank=1.238176,Degree=2" in out   # SURVEY 8c known answers
