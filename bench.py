@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the second, all-f64 run whose numbers go into `f64_messages`")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="N > 1: the iteration loop in C++ calling RCCL directly (csrc/dist.hip, default) or in Python over torch.distributed (graphtap_amd/dist.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on a 1-GPU box)")
     ap.add_argument("--spmv", choices=["pb", "pb_f32msg", "edge"], default=os.environ.get("GRAPHTAP_SPMV", "pb_f32msg"),
                     help="SpMV implementation (gt_spmv_variant): propagation blocking (default), the same with f32 messages, or the edge-atomic baseline")
@@ -154,6 +156,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.driver == "native" and args.backend == "nccl":
+            from graphtap_amd import dist_native
+            dist_native.init(rank, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -194,7 +199,7 @@ def main():
         VR.execute(args.steps)
         barrier()
         dt = time.perf_counter() - t0
-        if not G.exchange:
+        if not G.exchange or VR.stats is not None and world > 1 and args.driver == "native" and args.backend == "nccl":
             spmv_ms, launches = VR.stats.spmv_ms, VR.stats.spmv_launches
         else:
             a, b = C.c_double(), C.c_uint32()
@@ -271,8 +276,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
-                   "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(i.nnzrows_global), "nnzcols": int(i.nnzcols_global),
+                   "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(G.nnzrows_global), "nnzcols": int(i.nnzcols_global),
                    "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if world > 1 else "single tile",
+                   "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if world > 1 else "C++ gt_program_execute",
                    "ingress_s": round(t_ingress, 3), "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
         "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter* + k_pb_gather<double,double> (one SpMV = this launch group)",
                                                   "pb_f32msg": "k_pb_scatter* + k_pb_gather<double,float> (one SpMV = this launch group)",
@@ -291,6 +297,8 @@ def main():
             out["cpu_baseline_port"] = port_b
     if world > 1:
         VR.free(); V.free(); G.free()
+        if args.driver == "native" and args.backend == "nccl":
+            dist_native.free()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -308,16 +308,28 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
         if (hipMemcpy(staged, edges, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(staged); delete g; gt_set_error("H2D copy of the edge list failed"); return GT_ERR_HIP; }
         dev_edges = staged;
     }
+    const bool verbose = getenv("GRAPHTAP_PB_STATS") != nullptr;
+    auto tick = [&](const char *what, std::chrono::steady_clock::time_point &t) {
+        if (!verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build] %s: %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    };
+    auto tb = std::chrono::steady_clock::now();
     int st = gt_ingest(g, dev_edges, m, weighted);
+    tick("ingest (TCSC tile-row)", tb);
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_graph_free(g); return st; }
     const char *env = getenv("GRAPHTAP_SPMV");
     g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : (env && strcmp(env, "pb_f32msg") == 0) ? GT_SPMV_PB_F32MSG : GT_SPMV_PB;
     st = gt_layout_build(g);
     if (st != GT_OK) { gt_graph_free(g); return st; }
+    tick("layout of x", tb);
     if (g->spmv_variant != GT_SPMV_EDGE) {
         st = gt_pb_build(g);
         if (st != GT_OK) { gt_graph_free(g); return st; }
+        tick("propagation-blocking streams", tb);
     }
     *out = g;
     return GT_OK;

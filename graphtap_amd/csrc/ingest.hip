@@ -6,7 +6,7 @@
 //   Matrix::init_filtering     src/mat/matrix.hpp:813-858, 861-1144 (I/IV/J/JV, classes)
 //   TCSC_BASE::populate        src/ds/compressed_column.hpp:371-417
 // with radix sorts / scans (rocPRIM through hipCUB) and a few streaming kernels.
-// Every rank sees the full edge list (replicated ingest) and keeps tile-row `rank`.
+// Every rank reads the full edge list (replicated read) and keeps -- compacted, before any sort -- tile-row `rank`.
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr uint64_t KEY_INVALID = ~0ull;
 constexpr int TPB = 256;
 
 inline unsigned grid_for(uint64_t n, int per_thread = 1) {
@@ -38,40 +37,63 @@ struct DevBuf {  // frees on scope exit: ingest scratch
 // self_loops; acyclic swap; transpose swap; insert; mirrored insert when !directed.
 __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f,
                          uint32_t nrows, uint32_t perm_a, uint32_t perm_mask, uint32_t H, uint32_t row_lo, uint32_t row_hi,
-                         uint64_t *__restrict__ keys, uint32_t *__restrict__ wts,
+                         uint64_t *__restrict__ keys, uint32_t *__restrict__ wts, uint64_t room /* capacity of keys / wts */,
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
                          uint8_t *__restrict__ needme /* [span] columns this tile-row reads, or null on one rank */,
                          uint8_t *__restrict__ needby /* [nranks][H] owned columns read by tile-row d, or null  */,
                          unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
-    const int slots = f.directed ? 1 : 2;
-    unsigned long long kept = 0, bad = 0, glob = 0;
-    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t row = rec[e * stride], col = rec[e * stride + 1];
-        uint32_t w = (stride == 3) ? rec[e * stride + 2] : 0;
-        uint64_t k0 = KEY_INVALID, k1 = KEY_INVALID;
-        if (row >= nrows || col >= nrows) {
-            bad++;
-        } else if (!(row == col && !f.self_loops)) {
-            if (f.acyclic && col < row) { uint32_t t = row; row = col; col = t; }
-            if (f.transpose) { uint32_t t = row; row = col; col = t; }
-            row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;   // internal ids (identity on one rank)
-            rowflag[row] = 1; colflag[col] = 1; glob++;
-            if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; kept++; if (needme) needme[col] = 1; }
-            if (needby && col >= row_lo && col < row_hi) needby[(uint64_t)(row / H) * H + (col - row_lo)] = 1;
-            if (!f.directed) {
-                rowflag[col] = 1; colflag[row] = 1; glob++;
-                if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; kept++; if (needme) needme[row] = 1; }
-                if (needby && row >= row_lo && row < row_hi) needby[(uint64_t)(col / H) * H + (row - row_lo)] = 1;
+    unsigned long long bad = 0, glob = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    // non-empty ROWS are only needed for the owned segment (compressed row ids are segment-local); the non-empty COLUMNS of
+    // every segment are needed everywhere (the exchange layout numbers a source segment's columns by compressed id)
+    const bool all_rows = (needby == nullptr);
+    auto below = [](uint64_t mk) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0)); };
+    // COMPACTING: only the entries of this rank's tile-row are written (a rank of p sorts ~m/p keys, not m). A wave
+    // reserves room for what it keeps with one atomic; the order of the output is therefore arbitrary, which the sort
+    // that follows does not care about (equal keys -- and, with weights, equal (key, weight) pairs -- are interchangeable).
+    const uint64_t m64 = (m + 63) & ~63ull;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m64; e += (uint64_t)gridDim.x * blockDim.x) {
+        bool keep0 = false, keep1 = false;
+        uint64_t k0 = 0, k1 = 0;
+        uint32_t w = 0;
+        if (e < m) {
+            uint32_t row = rec[e * stride], col = rec[e * stride + 1];
+            w = (stride == 3) ? rec[e * stride + 2] : 0;
+            if (row >= nrows || col >= nrows) {
+                bad++;
+            } else if (!(row == col && !f.self_loops)) {
+                if (f.acyclic && col < row) { uint32_t t = row; row = col; col = t; }
+                if (f.transpose) { uint32_t t = row; row = col; col = t; }
+                row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;   // internal ids (identity on one rank)
+                // test before set: a vertex has ~16 records on average, so 15 of 16 visits find the flag set and a cached read
+                // replaces a scattered one-byte write (read-modify-write of a sector at the memory side: 202 -> see DESIGN ms
+                // for a tile-row of 8 of R-MAT-26, whose hashed ids make every access random)
+                auto set = [](uint8_t *__restrict__ flags, uint64_t i) { if (!flags[i]) flags[i] = 1; };
+                if (all_rows || (row >= row_lo && row < row_hi)) set(rowflag, row);
+                set(colflag, col); glob++;
+                if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; keep0 = true; if (needme) set(needme, col); }
+                if (needby && col >= row_lo && col < row_hi) set(needby, (uint64_t)(row / H) * H + (col - row_lo));
+                if (!f.directed) {
+                    if (all_rows || (col >= row_lo && col < row_hi)) set(rowflag, col);
+                    set(colflag, row); glob++;
+                    if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; keep1 = true; if (needme) set(needme, row); }
+                    if (needby && row >= row_lo && row < row_hi) set(needby, (uint64_t)(col / H) * H + (row - row_lo));
+                }
             }
         }
-        keys[e * slots] = k0;
-        if (wts) wts[e * slots] = w;
-        if (slots == 2) { keys[e * 2 + 1] = k1; if (wts) wts[e * 2 + 1] = w; }
+        const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+        const uint32_t n0 = (uint32_t)__popcll((unsigned long long)b0), n1 = (uint32_t)__popcll((unsigned long long)b1);
+        if (n0 + n1) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)(n0 + n1));
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+            if (keep0) { const uint64_t o = base + below(b0); if (o < room) { keys[o] = k0; if (wts) wts[o] = w; } }
+            if (keep1) { const uint64_t o = base + n0 + below(b1); if (o < room) { keys[o] = k1; if (wts) wts[o] = w; } }
+        }
     }
     // one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) { kept += __shfl_down(kept, o); bad += __shfl_down(bad, o); glob += __shfl_down(glob, o); }
-    if ((threadIdx.x & 63) == 0) {
-        if (kept) atomicAdd(&counters[0], kept);
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_down(bad, o); glob += __shfl_down(glob, o); }
+    if (lane == 0) {
         if (bad) atomicAdd(&counters[1], bad);
         if (glob) atomicAdd(&counters[2], glob);
     }
@@ -99,7 +121,6 @@ __global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint
                              const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[i];
-        if (k == KEY_INVALID) continue;
         const uint32_t col = (uint32_t)(k >> 32);
         const uint32_t c = tab ? local_col(tab, Scol, Sneed, H, T, p, col) : Scol[col];   // one rank: the compressed column id
         keys[i] = ((uint64_t)c << 32) | (uint32_t)k;
@@ -234,8 +255,12 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     const bool multi = p > 1 || g->force_exchange;
 
     DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby;
-    ING_ALLOC(keys, cap * 8); ING_ALLOC(keys2, cap * 8);
-    if (weighted) { ING_ALLOC(wts, cap * 4); ING_ALLOC(wts2, cap * 4); }
+    // Room for the kept entries: everything on one rank; on several, the hashed id space spreads the entries evenly, so
+    // 1.25 x the mean share (+ slack for small graphs) is reserved and the pass is repeated with the exact count in the
+    // rare case it does not fit (a multi-GB hipMalloc is not free: 8.6 GB for every rank of 8 at R-MAT-26 otherwise).
+    uint64_t room = (p == 1) ? cap : std::min<uint64_t>(cap, cap / p + cap / (4 * p) + 65536);
+    ING_ALLOC(keys, room * 8);
+    if (weighted) ING_ALLOC(wts, room * 4);
     ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
     ING_ALLOC(Srow, (span + 1) * 4); ING_ALLOC(Scol, (span + 1) * 4);
     ING_ALLOC(counters, 8 * sizeof(unsigned long long));
@@ -249,15 +274,22 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         ING_HIP(hipMemsetAsync(needby.p, 0, span + 1, s));
     }
 
-    if (m)
+    unsigned long long hc[3] = {0, 0, 0};
+    for (int attempt = 0; attempt < 2 && m; attempt++) {
         k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
-                                             keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr,
+                                             keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
                                              multi ? needme.as<uint8_t>() : nullptr, multi ? needby.as<uint8_t>() : nullptr,
                                              counters.as<unsigned long long>());
-    unsigned long long hc[3];
-    ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-    ING_HIP(hipStreamSynchronize(s));
+        ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+        ING_HIP(hipStreamSynchronize(s));
+        if (hc[0] <= room) break;
+        // did not fit (nothing was written past `room`): exact size, second pass (flags are idempotent)
+        room = hc[0];
+        (void)hipFree(keys.p); keys.p = nullptr; ING_ALLOC(keys, room * 8);
+        if (weighted) { (void)hipFree(wts.p); wts.p = nullptr; ING_ALLOC(wts, room * 4); }
+        ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
+    }
     if (hc[1]) {
         gt_set_error("%llu edge record(s) name a vertex id > num_vertices=%u (the reference overflows its tile grid silently, "
                      "src/mat/matrix.hpp:218-220; this library rejects the input)", hc[1], g->info.num_vertices);
@@ -310,7 +342,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     g->info.nnzrows = segr[k + 1] - segr[k];
     g->info.nnzcols = segc[k + 1] - segc[k];
     g->info.seg_stride = seg_stride;
-    g->info.nnzrows_global = segr[p];
+    g->info.nnzrows_global = multi ? g->info.nnzrows : segr[p];   // several ranks: only the owned rows are flagged; the driver sums
     g->info.nnzcols_global = segc[p];
     GT_REQUIRE((uint64_t)p * seg_stride < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "column id space exceeds 32 bits");
     g->send_counts.assign((size_t)K * p, 0); g->recv_counts.assign((size_t)K * p, 0);
@@ -382,31 +414,33 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     g->info.ncols_local = g->ncols_total;
     g->info.send_elems = (uint32_t)g->send_elems;
 
-    if (cap) k_remap_cols<<<grid_for(cap), TPB, 0, s>>>(keys.as<uint64_t>(), cap, Scol.as<uint32_t>(), multi ? Sneed.as<uint32_t>() : nullptr,
+    if (nvalid) k_remap_cols<<<grid_for(nvalid), TPB, 0, s>>>(keys.as<uint64_t>(), nvalid, Scol.as<uint32_t>(), multi ? Sneed.as<uint32_t>() : nullptr,
                                                         multi ? rtab_d.as<BlockTab>() : nullptr, H, T, p);
     // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
-    // so that the first copy of a duplicate (row,col) carries its minimum weight. Invalid keys sink
-    // to the end. Radix sort is stable.
+    // so that the first copy of a duplicate (row,col) carries its minimum weight. Only the nvalid kept
+    // entries are sorted (k_expand compacts). Radix sort is stable.
     uint64_t *sorted_keys = keys.as<uint64_t>();
     uint32_t *sorted_wts = weighted ? wts.as<uint32_t>() : nullptr;
-    if (cap) {
+    if (nvalid) {
+        ING_ALLOC(keys2, nvalid * 8);
+        if (weighted) ING_ALLOC(wts2, nvalid * 4);
         size_t tb1 = 0, tb2 = 0;
         hipcub::DoubleBuffer<uint64_t> dk(keys.as<uint64_t>(), keys2.as<uint64_t>());
         if (weighted) {
             hipcub::DoubleBuffer<uint32_t> dw(wts.as<uint32_t>(), wts2.as<uint32_t>());
-            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, dw, dk, cap, 0, 32, s));
-            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, dk, dw, cap, 0, 64, s));
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, dw, dk, nvalid, 0, 32, s));
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, dk, dw, nvalid, 0, 64, s));
             DevBuf st; ING_ALLOC(st, std::max(tb1, tb2));
             size_t tb = std::max(tb1, tb2);
-            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dw, dk, cap, 0, 32, s));   // by weight
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dw, dk, nvalid, 0, 32, s));   // by weight
             tb = std::max(tb1, tb2);
-            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, dw, cap, 0, 64, s));   // then by (col,row)
+            ING_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, dw, nvalid, 0, 64, s));   // then by (col,row)
             ING_HIP(hipStreamSynchronize(s));
             sorted_keys = dk.Current(); sorted_wts = dw.Current();
         } else {
-            ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, dk, cap, 0, 64, s));
+            ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, dk, nvalid, 0, 64, s));
             DevBuf st; ING_ALLOC(st, tb1);
-            ING_HIP(hipcub::DeviceRadixSort::SortKeys(st.p, tb1, dk, cap, 0, 64, s));
+            ING_HIP(hipcub::DeviceRadixSort::SortKeys(st.p, tb1, dk, nvalid, 0, 64, s));
             ING_HIP(hipStreamSynchronize(s));
             sorted_keys = dk.Current();
         }

@@ -106,14 +106,15 @@ class Graph:
         self.info = GraphInfo()
         check(lib().gt_graph_info_get(self._h, C.byref(self.info)))
         self.nnz_global = int(self.info.nnz_local)
+        self.nnzrows_global = int(self.info.nnzrows_global)
         if nranks > 1 and world()[1] == nranks:   # explicit rank/nranks without a process group: caller sums
             import torch
             import torch.distributed as dist
-            t = torch.tensor([self.nnz_global], dtype=torch.int64)
+            t = torch.tensor([self.nnz_global, int(self.info.nnzrows)], dtype=torch.int64)
             if dist.get_backend() == "nccl":
                 t = t.cuda()
             dist.all_reduce(t)
-            self.nnz_global = int(t.item())
+            self.nnz_global, self.nnzrows_global = int(t[0]), int(t[1])
         return self
 
     def vertex_ids(self):

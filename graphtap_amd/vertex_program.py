@@ -21,6 +21,11 @@ from ._lib import (GT_BFS, GT_CC, GT_COL, GT_DEG, GT_INF, GT_PR, GT_ROW, GT_SSSP
 from .graph import _TCSC_CF_
 
 _ROW_, _COL_ = GT_ROW, GT_COL   # Ordering_type, vp:17-21
+
+
+def _native_handle():
+    from . import dist_native
+    return dist_native.handle()
 INF = GT_INF
 
 
@@ -185,6 +190,9 @@ class Vertex_Program:
             check(lib().gt_program_execute(h, self.num_iterations, C.byref(st)))
             self.stats = st
             self.converged = bool(st.converged)
+        elif _native_handle() is not None:   # the C++ driver (csrc/dist.hip): RCCL called from the library
+            from . import dist_native
+            _, self.converged, self.stats = dist_native.execute(self, self.num_iterations)
         else:
             import torch
             from . import dist as gdist

@@ -129,12 +129,13 @@ def nccl_world1(gt):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("slices,fuse", [(2, "1"), (4, "0"), (1, "1")])
-def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slices, fuse, monkeypatch):
+@pytest.mark.parametrize("slices,fuse,driver", [(2, "1", "python"), (4, "0", "python"), (1, "1", "python"), (2, "1", "native"), (4, "0", "native")])
+def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slices, fuse, driver, monkeypatch):
     """World size 1 over RCCL with the exchange layout forced on (GRAPHTAP_FORCE_EXCHANGE): dist.run issues the K
     all_to_all_single calls on device tensors (async_op), waits per slice, drives gt_program_combine_slice on the
     helper streams, the fused applicator and the torch-owned x / send buffers -- everything an N-GPU run executes
-    except a second peer. Results must equal the plain single-rank engine's (gt_program_execute)."""
+    except a second peer. Results must equal the plain single-rank engine's (gt_program_execute). driver = native runs the
+    same through the C++ loop of csrc/dist.hip (bench.py's default for N > 1)."""
     from graphtap_amd.rmat import rmat_edges
     scale, nv = 17, 1 << 17
     w = rmat_edges(scale, 16, 11, weighted=True); e = np.ascontiguousarray(w[:, :2])
@@ -169,7 +170,15 @@ def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slic
         out["sssp"] = (P.V, P.iteration, P.checksum(out=None)); P.free(); G.free()
         return out
 
-    got, ref = apps(True), apps(False)
+    if driver == "native":   # the C++ loop (gt_dist_execute) instead of graphtap_amd.dist.run; the unique id travels over torch's group
+        from graphtap_amd import dist_native
+        dist_native.init()
+    try:
+        got = apps(True)
+    finally:
+        if driver == "native":
+            dist_native.free()
+    ref = apps(False)
     for k in ref:
         (gv, git, gcs), (rv, rit, rcs) = got[k], ref[k]
         if k == "prc_pb_f32msg":
