@@ -265,7 +265,7 @@ int gt_rmat_generate(void *dev_out, int scale, uint64_t seed, int weighted, uint
 // ---- graph
 int gt_graph_free(gt_graph *g) {
     if (!g) return GT_OK;
-    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx, g->xslot, g->XV, g->R2X, g->x_scratch};
+    void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx, g->xslot, g->xcol, g->XV, g->R2X, g->x_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     gt_pb_free(g->pb);
     delete g;
@@ -391,7 +391,8 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own};
+    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+                    p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slice_in) (void)hipEventDestroy(e);
@@ -474,6 +475,7 @@ static int init_common(gt_program *p) {
     hipStream_t s = p->stream;
     static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
     p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter;
+    p->last_active = (p->prm.kind == GT_BFS || p->prm.kind == GT_SSSP) ? 1 : ~0ull;   // the root alone is active (bfs.h:37-50, sssp.h:33-42)
     switch (p->prm.kind) {
         case GT_DEG:  // deg.h:31-34
             GT_HIP(hipMemsetAsync(p->s0, 0, (uint64_t)H * 4, s));
@@ -501,6 +503,7 @@ static int init_common(gt_program *p) {
     // accumulators: init_nonstationary fills y with infinity() (vp:625-635); stationary y is zeroed per combine
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
+    if (!p->stationary && p->prm.order == GT_ROW) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
     p->initialized = true;
     return pr_pack_state(p);
 }
@@ -640,7 +643,9 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         gt_pr_epilogue epi{};
         const bool fuse = hi >= K && fused_epilogue(p, &epi);
         if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr);
+        bool sparse_done = false;
+        if (!p->stationary && lo == 0 && hi >= K) { int st = gt_spmspv_try(p, s, &sparse_done); if (st != GT_OK) return st; }
+        int st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr);
         if (st != GT_OK) return st;
         p->fused = fuse;
         if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
@@ -774,7 +779,8 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         GT_HIP(hipMemcpyAsync(&h, p->d_active, sizeof(h), hipMemcpyDeviceToHost, s));
         GT_HIP(hipStreamSynchronize(s));
         *active = h;
-    }
+        p->last_active = h;
+    } else p->last_active = ~0ull;
     return GT_OK;
 }
 
@@ -797,31 +803,33 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0;
     GT_HIP(hipStreamSynchronize(s));
     auto t0 = std::chrono::steady_clock::now();
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
     // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
     const bool phase_timing = stats != nullptr && getenv("GRAPHTAP_TIMING") != nullptr;
     const bool fuse_apply = fuse_enabled();
-    double t_sg = 0, t_cb = 0, t_ap = 0;
+    double t_sg = 0, t_cb = 0, t_ap = 0, q_sg = 0, q_cb = 0, q_ap = 0;
+    uint32_t samples = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
-    auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc) -> int {
+    auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc, double &sq) -> int {
         if (phase_timing) GT_HIP(hipStreamSynchronize(s));
-        auto t2 = now(); acc += std::chrono::duration<double, std::milli>(t2 - t).count(); t = t2;
+        auto t2 = now(); const double ms = std::chrono::duration<double, std::milli>(t2 - t).count(); acc += ms; sq += ms * ms; t = t2;
         return GT_OK;
     };
     for (;;) {
         auto tp = now();
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
-        st = lap(tp, t_sg); if (st != GT_OK) return st;
+        st = lap(tp, t_sg, q_sg); if (st != GT_OK) return st;
         // PageRank: apply follows combine at once, so phase 2 may apply the rows whose sums it completes (pb.hip)
         p->fuse_armed = fuse_apply && p->prm.kind == GT_PR && !p->converged; p->fuse_iters = iters; p->fuse_count = check;
         st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
-        st = lap(tp, t_cb); if (st != GT_OK) return st;
+        st = lap(tp, t_cb, q_cb); if (st != GT_OK) return st;
         uint64_t active = 0;
         st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
-        st = lap(tp, t_ap); if (st != GT_OK) return st;
+        st = lap(tp, t_ap, q_ap); if (st != GT_OK) return st;
+        samples++;
         if (check) {
             if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
         } else if (p->iteration >= iters) break;
@@ -833,7 +841,9 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->iterations = p->iteration; stats->converged = p->converged;
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
+        stats->scatter_gather_sq = q_sg; stats->combine_sq = q_cb; stats->apply_sq = q_ap; stats->phase_samples = samples;
         stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
+        stats->spmspv_iterations = p->spmspv_iters;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

@@ -64,6 +64,7 @@ struct gt_graph {
     uint32_t x_len = 0;            // slots of x
     uint32_t ndw = 0;              // dense (aggregating, GT_PB_WINDOW wide) windows; the rest are sparse windows
     uint32_t *xslot = nullptr;     // [nnzcols] compressed column -> slot of x, or null = identity
+    uint32_t *xcol = nullptr;      // [x_len]   slot -> compressed column (inverse of xslot), ~0u for an unused slot, or null = identity
     uint32_t *XV = nullptr;        // [x_len]   slot -> local vertex (what JC is for the identity layout), ~0u for an unused slot
     uint32_t *R2X = nullptr;       // [nnzrows] compressed row -> slot of the same vertex's column, ~0u if none (R2C through xslot)
     void *x_scratch = nullptr;     // [x_len] x 8 B: gt_spmv's copy of a caller's compressed-order x in slot order
@@ -119,6 +120,14 @@ struct gt_program {
     // sliced combine (several ranks): phase 1 of slice k runs on helper stream k % size so that the tail of one slice
     // overlaps the start of the next (and, in the pipelined driver, the exchange of the later slices)
     // gt_program_execute: PageRank's apply of this iteration is fused into phase 2 for the row bins one workgroup owns
+    // sparse frontier (min programs): when the active columns hold few entries the SpMV runs as a frontier-driven SpMSpV
+    // (kernels.hip) instead of the propagation-blocking pass
+    uint32_t *fr_col = nullptr, *fr_val = nullptr, *fr_off = nullptr;   // [fr_cap] active columns, their messages, entry offsets
+    void *fr_tmp = nullptr; size_t fr_tmp_bytes = 0;                    // scan scratch
+    uint32_t fr_cap = 0;
+    unsigned long long *d_frontier = nullptr;                           // [2] active columns, entries in them
+    uint64_t last_active = ~0ull;                                       // vertices the previous apply() activated (converge mode), or ~0 if unknown
+    uint32_t spmspv_iters = 0;                                          // iterations of the current execute() that took the sparse path
     bool fuse_armed = false, fused = false;   // armed before combine; fused = the combine of this iteration did it
     uint32_t fuse_iters = 0;
     bool fuse_count = false;
@@ -172,6 +181,11 @@ __host__ __device__ inline uint32_t gt_vid_of(const gt_vidmap &m, uint64_t u) {
 inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv, g->perm_mask, g->nint, g->info.nrows}; }
 
 // kernels.hip
+// Frontier-driven SpMSpV of the min semirings (the reference's sparse path, vp:754-784 and 1475-1489): y[r] = min(y[r], x[c] (+ w))
+// over the entries of the ACTIVE columns only. Counts first; runs only if they hold at most nnz / 4096 entries (or GRAPHTAP_SPMSPV
+// forces it); *done tells whether the SpMV is complete.
+int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
+int gt_spmspv_reserve(gt_program *p, uint32_t nact);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
 // min programs skip chunks without an active column (activity filtering)

@@ -8,6 +8,10 @@
 // (4 B more per entry than TCSC's JA walk, but perfectly balanced under R-MAT skew), the
 // accumulate is a device-scope atomic on y. It is the correctness baseline that the blocked
 // kernels are checked against; see DESIGN.md for the roofline of each.
+#include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
+
 #include "gt_internal.h"
 
 namespace {
@@ -100,5 +104,123 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
             return GT_ERR_INVALID;
     }
     GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+
+// ------------------------------------------------------------------ sparse frontier: SpMSpV of the min semirings
+namespace {
+
+// active columns (message != infinity()) of the message vector and the entries they hold
+__global__ void k_frontier_count(const uint32_t *__restrict__ x, uint32_t x_len, const uint32_t *__restrict__ xcol, const uint32_t *__restrict__ JA,
+                                 unsigned long long *__restrict__ out) {
+    unsigned long long n = 0, e = 0;
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < x_len; sl += gridDim.x * blockDim.x) {
+        if (x[sl] == GT_INF) continue;
+        const uint32_t c = xcol ? xcol[sl] : sl;
+        if (c == 0xFFFFFFFFu) continue;
+        n++; e += JA[c + 1] - JA[c];
+    }
+    for (int o = 32; o > 0; o >>= 1) { n += __shfl_down(n, o); e += __shfl_down(e, o); }
+    if ((threadIdx.x & 63) == 0 && n) { atomicAdd(&out[0], n); atomicAdd(&out[1], e); }
+}
+__global__ void k_frontier_list(const uint32_t *__restrict__ x, uint32_t x_len, const uint32_t *__restrict__ xcol, const uint32_t *__restrict__ JA,
+                                unsigned int *__restrict__ cursor, uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg) {
+    const uint32_t n64 = (x_len + 63) & ~63u, lane = threadIdx.x & 63;
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n64; sl += gridDim.x * blockDim.x) {
+        uint32_t c = 0xFFFFFFFFu, v = GT_INF;
+        if (sl < x_len) { v = x[sl]; if (v != GT_INF) c = xcol ? xcol[sl] : sl; }
+        const bool act = c != 0xFFFFFFFFu;
+        const uint64_t b = __ballot(act);
+        if (!b) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned)__popcll((unsigned long long)b));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (act) {
+            const uint32_t o = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            col[o] = c; val[o] = v; deg[o] = JA[c + 1] - JA[c];
+        }
+    }
+}
+// one thread per entry of an active column: the column is found by bisection of the entry offsets
+template <bool WEIGHTED>
+__global__ void k_spmspv_min(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ off, uint32_t nact,
+                             uint64_t total, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
+                             uint32_t *__restrict__ y) {
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nact;   // last i with off[i] <= t
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t e = JA[col[lo]] + (uint32_t)(t - off[lo]);
+        const uint32_t r = IA[e];
+        const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
+        if (m < y[r]) atomicMin(&y[r], m);
+    }
+}
+
+}  // namespace
+
+// buffers of the sparse path, sized for frontiers of up to `nact` columns (called at initialize() so that no allocation
+// falls into the iteration loop)
+int gt_spmspv_reserve(gt_program *p, uint32_t nact) {
+    if (!p->d_frontier) GT_HIP(hipMalloc((void **)&p->d_frontier, 4 * sizeof(unsigned long long)));
+    if (p->fr_cap < nact + 1) {
+        for (void *q : {(void *)p->fr_col, (void *)p->fr_val, (void *)p->fr_off}) if (q) GT_HIP(hipFree(q));
+        p->fr_col = p->fr_val = p->fr_off = nullptr; p->fr_cap = 0;
+        const uint64_t cap = (uint64_t)nact + nact / 2 + 1024;
+        GT_HIP(hipMalloc((void **)&p->fr_col, cap * 4)); GT_HIP(hipMalloc((void **)&p->fr_val, cap * 4)); GT_HIP(hipMalloc((void **)&p->fr_off, cap * 4));
+        p->fr_cap = (uint32_t)cap;
+    }
+    size_t tb = 0;
+    GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, p->fr_cap, (hipStream_t)0));
+    if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+    return GT_OK;
+}
+
+int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
+    *done = false;
+    const gt_graph *g = p->g;
+    if (p->semiring != GT_MIN_U32 && p->semiring != GT_MINPLUS_U32) return GT_OK;
+    const char *env = getenv("GRAPHTAP_SPMSPV");               // "0": never, "1": whenever there is a frontier, unset: by size
+    if (env && atoi(env) == 0) return GT_OK;
+    const uint64_t nnz = g->info.nnz_local;
+    if (nnz == 0) return GT_OK;
+    const bool force = env && atoi(env) == 1;
+    // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
+    // count the converge-mode driver reads anyway) activated few vertices
+    if (!force && p->last_active > 16384) return GT_OK;
+    if (!p->d_frontier) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
+    GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
+    const uint32_t x_len = (uint32_t)p->x_elems;
+    const unsigned grid = (unsigned)std::min<uint64_t>((x_len + TPB - 1) / TPB + 1, 4096);
+    k_frontier_count<<<grid, TPB, 0, s>>>((const uint32_t *)p->x, x_len, g->xcol, g->JA, p->d_frontier);
+    unsigned long long h[2] = {0, 0};
+    GT_HIP(hipMemcpyAsync(h, p->d_frontier, sizeof(h), hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    if (h[0] == 0 || h[1] == 0) { *done = true; return GT_OK; }  // empty frontier (or active columns without entries here): y keeps its running minima
+    // The reference switches at 0.6 of the columns (vp:769). Here the streaming pass already skips every window without an
+    // active column (pb.hip), so the frontier-driven kernel only pays for tiny frontiers -- measured on BFS / CC / SSSP of
+    // R-MAT-26: at <= nnz/64 entries 5 of 7 BFS iterations took it and the run was 37 % SLOWER (18.3 vs 13.3 ms; count +
+    // compaction + scan + device atomics against a pass that exits at once on idle windows) -- hence the low default.
+    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 4096;
+    if (!force && h[1] > nnz / frac) return GT_OK;
+    GT_REQUIRE(h[0] < 0xFFFFFFFFull && h[1] < (1ull << 40), GT_ERR_UNSUPPORTED, "frontier too large for the sparse path");
+    const uint32_t nact = (uint32_t)h[0];
+    if (p->fr_cap < nact + 1) { int st = gt_spmspv_reserve(p, nact); if (st != GT_OK) return st; }
+    GT_REQUIRE(h[1] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "frontier entry offsets exceed 32 bits");
+    unsigned int *cursor = (unsigned int *)(p->d_frontier + 2);
+    k_frontier_list<<<grid, TPB, 0, s>>>((const uint32_t *)p->x, x_len, g->xcol, g->JA, cursor, p->fr_col, p->fr_val, p->fr_off);
+    {   // degrees -> exclusive offsets, in place
+        size_t tb = 0;
+        GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, nact, s));
+        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+        GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
+    }
+    const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
+    if (p->semiring == GT_MINPLUS_U32)
+        k_spmspv_min<true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y);
+    else
+        k_spmspv_min<false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y);
+    GT_HIP(hipGetLastError());
+    p->spmspv_iters++;
+    *done = true;
     return GT_OK;
 }

@@ -130,8 +130,9 @@ __global__ void k_slots_tail(const uint32_t *__restrict__ tailflag, const uint32
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x)
         if (tailflag[c]) xslot[c] = base + tailpos[c];
 }
-__global__ void k_slot_vertices(const uint32_t *__restrict__ xslot, const uint32_t *__restrict__ JC, uint32_t nc, uint32_t *__restrict__ XV) {
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) XV[xslot[c]] = JC[c];
+__global__ void k_slot_vertices(const uint32_t *__restrict__ xslot, const uint32_t *__restrict__ JC, uint32_t nc, uint32_t *__restrict__ XV,
+                                uint32_t *__restrict__ xcol) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x) { XV[xslot[c]] = JC[c]; xcol[xslot[c]] = c; }
 }
 __global__ void k_row_slots(const uint32_t *__restrict__ xslot, const uint32_t *__restrict__ R2C, uint32_t nr, uint32_t *__restrict__ R2X) {
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
@@ -814,6 +815,7 @@ int gt_layout_build(gt_graph *g) {
     GT_REQUIRE(xl < 0xFFFFFFF0ull, GT_ERR_UNSUPPORTED, "message vector exceeds 32-bit slot ids");
     LAY_HIP(hipMalloc((void **)&g->xslot, (uint64_t)nc * 4));
     LAY_HIP(hipMalloc((void **)&g->XV, std::max<uint64_t>(xl, 1) * 4));
+    LAY_HIP(hipMalloc((void **)&g->xcol, std::max<uint64_t>(xl, 1) * 4));
     LAY_HIP(hipMalloc((void **)&g->R2X, (uint64_t)std::max(nr, 1u) * 4));
     if (nhub) {
         for (Buf *b : {&key, &key2, &col, &col2}) LAY_HIP(hipMalloc(&b->p, (uint64_t)nhub * 4));
@@ -828,7 +830,8 @@ int gt_layout_build(gt_graph *g) {
     }
     k_slots_tail<<<grid_for(nc), TPB, 0, s>>>((const uint32_t *)tailflag.p, (const uint32_t *)tailpos.p, nc, ndw * W, g->xslot);
     LAY_HIP(hipMemsetAsync(g->XV, 0xFF, std::max<uint64_t>(xl, 1) * 4, s));
-    k_slot_vertices<<<grid_for(nc), TPB, 0, s>>>(g->xslot, g->JC, nc, g->XV);
+    LAY_HIP(hipMemsetAsync(g->xcol, 0xFF, std::max<uint64_t>(xl, 1) * 4, s));
+    k_slot_vertices<<<grid_for(nc), TPB, 0, s>>>(g->xslot, g->JC, nc, g->XV, g->xcol);
     if (nr) k_row_slots<<<grid_for(nr), TPB, 0, s>>>(g->xslot, g->R2C, nr, g->R2X);
     LAY_HIP(hipStreamSynchronize(s));
     LAY_HIP(hipGetLastError());

@@ -36,14 +36,24 @@ def read_edge_file(path, weighted):
         head = f.read(4096)
     is_text = len(head) > 0 and all((32 <= b < 127) or b in (9, 10, 13) for b in head)
     if is_text:
-        rows = []
-        with open(path, "r") as f:
-            for line in f:
-                if not line.strip() or line[0] in "#%":   # graph.hpp:208-213
+        # parread_text (graph.hpp:195-304), the same rule as include/graphtap_amd.hpp parse_text: leading '#' / '%' / empty
+        # lines are skipped, every other line is "row col[ weight]" separated by single spaces (another column count, a
+        # non-digit or an id above 2^32 - 1 is "read() failure", :250-257), the list ends at the first empty line; comment
+        # lines further down are skipped too.
+        rows, started = [], False
+        with open(path, "rb") as f:
+            for raw in f.read().split(b"\n"):
+                line = raw[:-1] if raw.endswith(b"\r") else raw
+                if not line:
+                    if started:
+                        break
                     continue
-                parts = line.split()
-                if len(parts) != stride:
-                    raise GraphTapError('read() failure "%s"' % line.strip())  # graph.hpp:250-257
+                if line[:1] in (b"#", b"%"):
+                    continue
+                started = True
+                parts = line.split(b" ")
+                if len(parts) != stride or not all(t.isdigit() and int(t) <= 0xFFFFFFFF for t in parts):
+                    raise GraphTapError('read() failure "%s"' % line.decode("ascii", "replace"))
                 rows.append([int(t) for t in parts])
         return np.asarray(rows, dtype=np.uint32).reshape(-1, stride)
     if size % (4 * stride) != 0:

@@ -146,6 +146,12 @@ typedef struct gt_exec_stats {
      * iterations of this call; phases are enqueued asynchronously, so they only add up to `seconds` when the
      * library is asked to drain the stream after each phase (environment GRAPHTAP_TIMING=1) */
     double scatter_gather_ms, combine_ms, apply_ms;
+    uint32_t spmspv_iterations; /* min programs: iterations whose frontier was small enough for the frontier-driven SpMSpV
+                                   (the reference's sparse path, vp:754-784, 1475-1489) instead of the streaming SpMV */
+    uint32_t phase_samples;     /* iterations behind the three phase sums (each phase is timed once per iteration)  */
+    /* sums of squares (ms^2) of the per-iteration phase times, for the reference's "sum: avg +/- std_dev" record
+     * (stats(), vp:2183-2190); like the sums only meaningful with GRAPHTAP_TIMING=1 */
+    double scatter_gather_sq, combine_sq, apply_sq;
 } gt_exec_stats;
 
 /* state fields for gt_program_copy_state */

@@ -231,8 +231,8 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
           G_(G), kind_(kind), order_(ot) {}
     virtual ~Vertex_Program() {}
 
-    void initialize() { check(gt_program_initialize(handle())); already_initialized_ = true; }
-    void initialize(Vertex_Program &other) { check(gt_program_initialize_from(handle(), other.handle())); already_initialized_ = true; }
+    void initialize() { const auto t0 = clock_(); check(gt_program_initialize(handle())); init_done_(t0); }
+    void initialize(Vertex_Program &other) { const auto t0 = clock_(); check(gt_program_initialize_from(handle(), other.handle())); init_done_(t0); }
     void execute(uint32_t num_iterations_ = 0) {  // vp:408-441
         num_iterations = num_iterations_;
         if (!already_initialized_) initialize();
@@ -244,9 +244,11 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
         iteration = stats.iterations;
         for (uint32_t i = first; i <= iteration; i++) GT_MASTER_PRINTF("Iteration:  %u\n", i);  // vp:422
         GT_MASTER_PRINTF("Execute time: %f seconds\n", stats.seconds);                          // vp:437
-        if (getenv("GRAPHTAP_TIMING"))   // the reference's -DTIMING record, vp:2145-2152 (sums only: one call, no per-iteration std-dev)
-            GT_MASTER_PRINTF("TIMING scatter_gather %f combine %f apply %f execute %f ms (SpMV kernels %f ms over %u launches)\n",
-                   stats.scatter_gather_ms, stats.combine_ms, stats.apply_ms, stats.seconds * 1e3, stats.spmv_ms, stats.spmv_launches);
+        // -DTIMING bookkeeping of the reference: one sample per phase and iteration (vp:640-684, 1018-1054, 1611-1637),
+        // the first execute()'s wall time (execute_time[0], vp:2143)
+        tm_.sg += stats.scatter_gather_ms; tm_.cb += stats.combine_ms; tm_.ap += stats.apply_ms;
+        tm_.sg2 += stats.scatter_gather_sq; tm_.cb2 += stats.combine_sq; tm_.ap2 += stats.apply_sq; tm_.n += stats.phase_samples;
+        if (tm_.execute_ms < 0) tm_.execute_ms = stats.seconds * 1e3;
     }
     void checksum() {  // vp:1927-1960
         uint64_t sc[2] = {0, 0};
@@ -277,6 +279,21 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
         const uint32_t limit = Env::nranks() > 1 ? G_.info.nrows : G_.info.tile_height;
         count = count < limit ? count : limit;
         fetch(count);
+        if (getenv("GRAPHTAP_TIMING") && tm_.n) {   // the reference's -DTIMING record, printed by display() (vp:2134-2152)
+            auto line = [&](const char *name, double sum, double sq) {
+                const double mean = sum / tm_.n, var = sq / tm_.n - mean * mean;
+                GT_MASTER_PRINTF("%s time (sum: avg +/- std_dev): %f: %f +/- %f ms\n", name, sum, mean, std::sqrt(var > 0 ? var : 0));
+            };
+            auto triple = [&](double sum, double sq) {
+                const double mean = sum / tm_.n, var = sq / tm_.n - mean * mean;
+                GT_MASTER_PRINTF(" %f %f %f", sum, mean, std::sqrt(var > 0 ? var : 0));
+            };
+            GT_MASTER_PRINTF("Init           time: %f ms\n", tm_.init_ms);
+            line("Scatter_gather", tm_.sg, tm_.sg2); line("Combine       ", tm_.cb, tm_.cb2); line("Apply         ", tm_.ap, tm_.ap2);
+            GT_MASTER_PRINTF("Execute        time: %f ms\n", tm_.execute_ms);
+            GT_MASTER_PRINTF("TIMING %f", tm_.init_ms); triple(tm_.sg, tm_.sg2); triple(tm_.cb, tm_.cb2); triple(tm_.ap, tm_.ap2);
+            GT_MASTER_PRINTF(" %f\n", tm_.execute_ms);
+        }
         for (uint32_t i = 0; i < count; i++) GT_MASTER_PRINTF("vertex[%u]:%s\n", i, print_state(i).c_str());
     }
     void free() {
@@ -321,6 +338,13 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
 
   protected:
     virtual void fetch(uint32_t count) = 0;
+    static std::chrono::steady_clock::time_point clock_() { return std::chrono::steady_clock::now(); }
+    void init_done_(std::chrono::steady_clock::time_point t0) {
+        already_initialized_ = true;
+        if (getenv("GRAPHTAP_TIMING")) check(gt_device_synchronize());
+        if (tm_.init_ms < 0) tm_.init_ms = std::chrono::duration<double, std::milli>(clock_() - t0).count();   // init_time[0]
+    }
+    struct { double init_ms = -1, execute_ms = -1, sg = 0, cb = 0, ap = 0, sg2 = 0, cb2 = 0, ap2 = 0; uint64_t n = 0; } tm_;
     Graph &G_;
     int kind_;
     Ordering_type order_;

@@ -4,6 +4,12 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch bundles its own HIP runtime (same SONAME as /opt/rocm's). Whichever copy a process loads first serves both
+# PyTorch and libgraphtap_amd.so; PyTorch's refuses to see the GPU behind the system copy ("No HIP GPUs are available"),
+# the other order works. Tests that use both (the torch.distributed drivers) therefore need torch imported first, whatever
+# subset of test files is collected.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -144,3 +144,29 @@ def test_mains_read_text_edge_lists(tmp_path):
         assert "Read %d edges" % (16384) in b.stdout
     r = run("cc", wtxt, 1024)      # three columns where cc expects two
     assert r.returncode == 1 and "read() failure" in r.stderr
+
+
+@pytest.mark.gpu
+def test_timing_record_has_the_references_format():
+    """GRAPHTAP_TIMING=1: display() prints the reference's -DTIMING record (vp:2134-2152) -- per-iteration mean +/- std_dev
+    of the three phases, first init and execute times, and the one-line TIMING summary. The format is pinned against the
+    record the unmodified reference printed for the same command (tests/golden/make_timing_golden.py); the numbers must be
+    self-consistent (TIMING repeats the lines above it; sum = 20 x mean for 20 iterations)."""
+    import re
+    exe = os.path.join(BIN, "pr")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "rmat10_1024.bin"), "1024", "20"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GRAPHTAP_TIMING="1"))
+    assert r.returncode == 0, r.stderr
+    out = r.stdout.splitlines()
+    i = max(k for k, l in enumerate(out) if l.startswith("Init           time:"))
+    rec = out[i:i + 6]
+    ref = open(os.path.join(GOLDEN, "timing_record_rmat10_pr20.txt")).read().splitlines()
+    shape = lambda lines: [re.sub(r"-?[0-9]+\.[0-9]{6}", "#", l) for l in lines]
+    assert shape(rec) == shape(ref), (rec, ref)
+    assert out[i + 6].startswith("vertex[0]:")
+    nums = [float(x) for x in rec[5].split()[1:]]
+    assert len(nums) == 11
+    flat = [float(x) for l in rec[:5] for x in re.findall(r"-?[0-9]+\.[0-9]{6}", l)]
+    assert flat == nums
+    for k in (1, 4, 7):   # sum, mean, std of scatter_gather / combine / apply over 20 iterations
+        assert abs(nums[k] - 20 * nums[k + 1]) <= 1e-4 * max(1.0, nums[k]) + 2e-5 and nums[k + 2] >= 0

@@ -57,7 +57,7 @@ def run_min(gt, app, edges, nv, root=0):
         G = gt.Graph(); G.load_edges(edges, nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
         P = gt.CC_Program(G, False, True, False, gt._ROW_)
     P.execute()
-    out = dict(P.V, iterations=P.iteration, checksum=P.checksum(out=None), display=P.display(out=None))
+    out = dict(P.V, iterations=P.iteration, checksum=P.checksum(out=None), display=P.display(out=None), stats=P.stats)
     P.free(); G.free()
     return out
 
@@ -224,6 +224,25 @@ def test_bfs_sssp_cc_bit_exact(gt, name, known_answers):
     assert (r["label"][:n] == c["np1_cc_a"]).all()
     ka = known_answers[name]["np1_cc"]
     assert (r["iterations"], r["checksum"]) == (ka["iterations"], (ka["checksum"], ka["reachable"]))
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+@pytest.mark.parametrize("name", CASES)
+def test_sparse_frontier_spmspv_is_bit_exact(gt, name, mode, known_answers, monkeypatch):
+    """The reference switches a non-stationary iteration to its sparse SpMSpV when few columns are active (vp:754-784,
+    1475-1489); here an iteration whose active columns hold <= nnz/64 entries runs the frontier-driven kernel
+    (kernels.hip) instead of the streaming pass. GRAPHTAP_SPMSPV=1 forces it for every iteration, =0 forbids it: labels
+    AND iteration counts must equal the reference's either way (y is a running minimum: the order of arrival is free)."""
+    monkeypatch.setenv("GRAPHTAP_SPMSPV", mode)
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
+    r = run_min(gt, "bfs", c["edges"], nv, c["root"])
+    assert (r["parent"][:n] == c["np1_bfs_a"]).all() and (r["hops"][:n] == c["np1_bfs_b"]).all() and r["iterations"] == k["np1_bfs"]["iterations"]
+    assert (r["stats"].spmspv_iterations > 0) == (mode == "1")
+    r = run_min(gt, "cc", c["edges"], nv)
+    assert (r["label"][:n] == c["np1_cc_a"]).all() and r["iterations"] == k["np1_cc"]["iterations"]
+    r = run_min(gt, "sssp", c["wedges"], nv, c["root"])
+    assert (r["distance"][:n] == c["np1_sssp_a"]).all() and r["iterations"] == k["np1_sssp"]["iterations"]
+    assert (r["stats"].spmspv_iterations > 0) == (mode == "1")
 
 
 def test_display_lines_match_survey_table(gt):

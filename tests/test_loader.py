@@ -26,6 +26,48 @@ def test_binary_and_text_files_parse_to_the_same_records(tmp_path):
         read_edge_file(str(bad), False)
 
 
+TRICKY = "# header\n\n% more\n0 1\n1 2\n# comment inside the list\n2 3\r\n3 4\n\n7 8\n8 9\n"   # the list ends at the first empty line
+
+
+def test_text_rule_is_the_references_parread_text(tmp_path):
+    """Same rule as the C++ front end (include/graphtap_amd.hpp parse_text), which follows parread_text (graph.hpp:195-304):
+    leading comment / empty lines skipped, single spaces, the list ends at the first empty line, ids checked."""
+    from graphtap_amd.graph import read_edge_file
+    from graphtap_amd import GraphTapError
+    t = tmp_path / "t.txt"; t.write_text(TRICKY)
+    assert read_edge_file(str(t), False).tolist() == [[0, 1], [1, 2], [2, 3], [3, 4]]
+    for bad in ("0  1\n", "0 1 \n", "0 x\n", "0 4294967296\n", "0 -1\n"):
+        b = tmp_path / "b.txt"; b.write_text("0 1\n" + bad)
+        with pytest.raises(GraphTapError, match="read\\(\\) failure"):
+            read_edge_file(str(b), False)
+    ok = tmp_path / "ok.txt"; ok.write_text("0 4294967295\n")
+    assert read_edge_file(str(ok), False).tolist() == [[0, 4294967295]]
+
+
+@pytest.mark.gpu
+def test_both_front_ends_read_a_text_list_the_same_way(tmp_path):
+    """The tricky list above through graphtap_amd.Graph.load (Python) and through apps/bin/cc (C++ shim): same graph."""
+    import os
+    import subprocess
+    import graphtap_amd as gt
+    from conftest import ROOT
+    gt._lib.require_gpu()
+    t = tmp_path / "t.txt"; t.write_text(TRICKY)
+    G = gt.Graph(); G.load(str(t), 16, 16, False, False, True, False, False, gt._2DT_, gt._TCSC_)
+    P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+    cs = P.checksum(out=None); it = P.iteration
+    assert P.V["label"][:10].tolist() == [0, 0, 0, 0, 0, 5, 6, 7, 8, 9]     # 7-8-9 were cut off with the empty line
+    P.free(); G.free()
+    r = subprocess.run([os.path.join(ROOT, "apps", "bin", "cc"), str(t), "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Read 4 edges" in r.stdout and "Iterations: %d" % it in r.stdout and "Value checksum: %d" % cs[0] in r.stdout
+    b = tmp_path / "b.txt"; b.write_text("0 1\n0  2\n")
+    r = subprocess.run([os.path.join(ROOT, "apps", "bin", "cc"), str(b), "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "read() failure" in r.stderr
+    with pytest.raises(gt.GraphTapError, match="read\\(\\) failure"):
+        gt.Graph().load(str(b), 16, 16, False, False, True, False, False, gt._2DT_, gt._TCSC_)
+
+
 @pytest.mark.gpu
 def test_graph_load_from_files(tmp_path):
     import graphtap_amd as gt

@@ -42,7 +42,7 @@ for app in args.apps.split(","):
     st = P.stats
     cs = P.checksum(out=None)
     print(json.dumps({"app": app, "scale": scale, "edge_factor": args.edge_factor, "root": int(P.root), "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
-                      "iterations": st.iterations, "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
+                      "iterations": st.iterations, "sparse_iterations": int(st.spmspv_iterations), "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
                       "spmv_ms_mean": st.spmv_ms / max(st.spmv_launches, 1), "ingress_s": round(ingress, 3),
                       "value_checksum": cs[0], "reachable": cs[1]}), flush=True)
     P.free(); G.free()
