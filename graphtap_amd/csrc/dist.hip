@@ -295,7 +295,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     hipStream_t s = p->stream;
     if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
     (void)gt_program_enable_timing(p, stats != nullptr);
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
     GT_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -326,7 +326,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double ms = 0; uint32_t n = 0;
         (void)gt_program_timing(p, &ms, &n, 1);
-        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters;
+        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered;
     }
     return GT_OK;
 }

@@ -645,7 +645,13 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
         bool sparse_done = false;
         if (!p->stationary && lo == 0 && hi >= K) { int st = gt_spmspv_try(p, s, &sparse_done); if (st != GT_OK) return st; }
-        int st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr);
+        // TCSC_CF computation filtering (compressed_column.hpp:671-708, vp:1264-1317): the entries of source rows matter on
+        // the last iteration only (never in converge mode, SURVEY trap 5); their chunks stay out until then
+        const bool cf_last = p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters;
+        const bool skip_source = p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF && p->cf_hint && !cf_last && gt_pb_source_entries(g) != 0 &&
+                                 !getenv("GRAPHTAP_NO_CF_FILTER");
+        if (skip_source) p->cf_filtered++;
+        int st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source);
         if (st != GT_OK) return st;
         p->fused = fuse;
         if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }
@@ -707,7 +713,7 @@ static bool fuse_enabled() {
 int gt_program_fuse_apply(gt_program *p, uint32_t num_iterations, int want_active) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "fuse_apply before initialize");
     p->fuse_armed = fuse_enabled() && p->prm.kind == GT_PR && !p->converged;
-    p->fuse_iters = num_iterations; p->fuse_count = want_active != 0;
+    p->fuse_iters = num_iterations; p->fuse_count = want_active != 0; p->cf_hint = true;
     return GT_OK;
 }
 int gt_program_enable_timing(gt_program *p, int on) {
@@ -739,7 +745,7 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     if (p->converged) { p->iteration++; p->fused = false; p->fuse_armed = false; if (active) *active = 0; return GT_OK; }
     unsigned long long *d_active = active ? p->d_active : nullptr;   // counted only when the caller wants it (converge mode)
     const bool fused = p->fused;   // phase 2 already applied the rows of its single-workgroup bins (and counted them)
-    p->fused = false; p->fuse_armed = false;
+    p->fused = false; p->fuse_armed = false; p->cf_hint = false;
     GT_REQUIRE(!fused || ((active != nullptr) == p->fuse_count && num_iterations == p->fuse_iters), GT_ERR_STATE,
                "apply() after a fused combine must use the arguments the fusion was armed with");
     if (d_active && !fused) GT_HIP(hipMemsetAsync(d_active, 0, sizeof(unsigned long long), s));
@@ -803,7 +809,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
     GT_HIP(hipStreamSynchronize(s));
     auto t0 = std::chrono::steady_clock::now();
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
@@ -823,7 +829,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
         st = lap(tp, t_sg, q_sg); if (st != GT_OK) return st;
         // PageRank: apply follows combine at once, so phase 2 may apply the rows whose sums it completes (pb.hip)
-        p->fuse_armed = fuse_apply && p->prm.kind == GT_PR && !p->converged; p->fuse_iters = iters; p->fuse_count = check;
+        p->fuse_armed = fuse_apply && p->prm.kind == GT_PR && !p->converged; p->fuse_iters = iters; p->fuse_count = check; p->cf_hint = true;
         st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
         st = lap(tp, t_cb, q_cb); if (st != GT_OK) return st;
         uint64_t active = 0;
@@ -843,7 +849,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
         stats->scatter_gather_sq = q_sg; stats->combine_sq = q_cb; stats->apply_sq = q_ap; stats->phase_samples = samples;
         stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
-        stats->spmspv_iterations = p->spmspv_iters;
+        stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

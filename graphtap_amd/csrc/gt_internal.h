@@ -128,6 +128,10 @@ struct gt_program {
     unsigned long long *d_frontier = nullptr;                           // [2] active columns, entries in them
     uint64_t last_active = ~0ull;                                       // vertices the previous apply() activated (converge mode), or ~0 if unknown
     uint32_t spmspv_iters = 0;                                          // iterations of the current execute() that took the sparse path
+    // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
+    // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
+    bool cf_hint = false;
+    uint32_t cf_filtered = 0;   // SpMVs of the current execute() that left the source rows' entries out
     bool fuse_armed = false, fused = false;   // armed before combine; fused = the combine of this iteration did it
     uint32_t fuse_iters = 0;
     bool fuse_count = false;
@@ -164,7 +168,8 @@ const uint8_t *gt_pb_bin_single(const gt_graph *g);   // [row bins] 1 = one phas
 uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
-               const gt_pr_epilogue *epi = nullptr);
+               const gt_pr_epilogue *epi = nullptr, bool skip_source = false);
+uint64_t gt_pb_source_entries(const gt_graph *g);   // entries in chunks of source rows (left out by PageRank/TCSC_CF until the last iteration)
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
 
@@ -191,4 +196,4 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
                    const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu,
-                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr);
+                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr, bool skip_source = false);

@@ -104,7 +104,12 @@ struct GroupRec { uint32_t k0, k[6], s; };   // 32 bytes, k-slots in output unit
 struct BinWork { uint32_t bin, k0, k1, single, c_lo, c_hi, pad0, pad1; };   // [c_lo, c_hi]: chunks whose runs overlap [k0, k1)
 
 // Windows of the message vector: ndw dense windows of W slots, then sparse windows of WS slots.
-struct WinGeom { uint32_t ndw, dense_end, nwin, x_len; };
+// Entries are further split by ROW CLASS (ncls = 2 on graphs without an exchange layout): class 1 = entries of SOURCE rows
+// (vertices with in-edges but no out-edges, R2C == ~0u). Under TCSC_CF the reference leaves them out of every iteration but
+// the last (computation filtering, compressed_column.hpp:671-708, vp:1264-1317); here they get chunks of their own -- the
+// "virtual window" of an entry is cls * nwin + window -- which PageRank/TCSC_CF does not launch until the last iteration.
+struct WinGeom { uint32_t ndw, dense_end, nwin, x_len, ncls, nvwin; };
+__device__ __forceinline__ uint32_t row_class(const uint32_t *__restrict__ srcbits, uint32_t r) { return srcbits ? (srcbits[r >> 5] >> (r & 31)) & 1u : 0u; }
 __host__ __device__ inline uint32_t win_of(const WinGeom &g, uint32_t slot) { return slot < g.dense_end ? slot / W : g.ndw + (slot - g.dense_end) / WS; }
 __host__ __device__ inline uint32_t win_col0(const WinGeom &g, uint32_t q) { return q < g.ndw ? q * W : g.dense_end + (q - g.ndw) * WS; }
 __device__ __forceinline__ uint32_t slot_of(const uint32_t *__restrict__ xslot, uint32_t c) { return xslot ? xslot[c] : c; }
@@ -156,6 +161,22 @@ __global__ void k_win_count(const uint32_t *__restrict__ JA, uint32_t nc, const 
         } else if (in && d) atomicAdd(&wcount[q], d);
     }
 }
+__global__ void k_source_bits(const uint32_t *__restrict__ R2C, uint32_t nr, uint32_t *__restrict__ bits) {
+    const uint32_t n64 = (nr + 63) & ~63u;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n64; r += gridDim.x * blockDim.x) {
+        const uint64_t b = __ballot(r < nr && R2C[r] == 0xFFFFFFFFu);
+        if ((threadIdx.x & 63) == 0) { bits[r >> 5] = (uint32_t)b; bits[(r >> 5) + 1] = (uint32_t)(b >> 32); }
+    }
+}
+// moves the entries of source rows from their window's count to the class-1 copy of the window
+__global__ void k_win_count_src(const uint32_t *__restrict__ JI, const uint32_t *__restrict__ IA, uint64_t nnz, const uint32_t *__restrict__ xslot,
+                                WinGeom geom, const uint32_t *__restrict__ srcbits, uint32_t *__restrict__ wcount) {
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * blockDim.x) {
+        if (!row_class(srcbits, IA[e])) continue;
+        const uint32_t q = win_of(geom, slot_of(xslot, JI[e]));
+        atomicSub(&wcount[q], 1u); atomicAdd(&wcount[geom.nwin + q], 1u);
+    }
+}
 // A window (dense: W slots, sparse: WS slots) is one chunk, unless it holds more than `ch` entries: such a window is cut into
 // several chunks by ROW BIN -- consecutive bins are packed into chunks of ~n/ceil(n/ch) entries, so every run holds
 // ALL entries its window has in that bin: as few and as long runs as the window allows and every same-row neighbour to
@@ -172,9 +193,10 @@ __global__ void k_win_sizes(const uint32_t *__restrict__ wcount, uint32_t nwin, 
 }
 // entries of every cut window per row bin, counted into plan[]
 __global__ void k_win_hist(const uint32_t *__restrict__ JI, const uint32_t *__restrict__ IA, uint64_t nnz, const uint32_t *__restrict__ xslot, WinGeom geom,
-                           uint32_t nbins, const uint32_t *__restrict__ cutflag, const uint32_t *__restrict__ cutidx, uint32_t *__restrict__ plan) {
+                           const uint32_t *__restrict__ srcbits, uint32_t nbins, const uint32_t *__restrict__ cutflag, const uint32_t *__restrict__ cutidx,
+                           uint32_t *__restrict__ plan) {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t q = win_of(geom, slot_of(xslot, JI[e]));
+        const uint32_t q = row_class(srcbits, IA[e]) * geom.nwin + win_of(geom, slot_of(xslot, JI[e]));
         if (cutflag[q]) atomicAdd(&plan[(uint64_t)cutidx[q] * nbins + (IA[e] >> RB)], 1u);
     }
 }
@@ -206,17 +228,17 @@ __global__ void k_win_plan(const uint32_t *__restrict__ wcount, uint32_t nwin, u
 }
 __global__ void k_fill_chunks(uint32_t nwin, const uint32_t *__restrict__ nsub, const uint32_t *__restrict__ cbase, WinGeom geom, uint32_t *__restrict__ ccol0) {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x)
-        for (uint32_t k = 0; k < nsub[q]; k++) ccol0[cbase[q] + k] = win_col0(geom, q);
+        for (uint32_t k = 0; k < nsub[q]; k++) ccol0[cbase[q] + k] = win_col0(geom, q % geom.nwin);
 }
 // sort key of every entry: (chunk, row bin, row inside the bin) -> runs come out sorted by (row, col)
 __global__ void k_keys(const uint32_t *__restrict__ JI, const uint32_t *__restrict__ IA, uint64_t nnz, const uint32_t *__restrict__ xslot, WinGeom geom,
-                       const uint32_t *__restrict__ cbase, const uint32_t *__restrict__ cutflag, const uint32_t *__restrict__ cutidx,
+                       const uint32_t *__restrict__ srcbits, const uint32_t *__restrict__ cbase, const uint32_t *__restrict__ cutflag, const uint32_t *__restrict__ cutidx,
                        const uint32_t *__restrict__ plan, uint32_t nbins, int binbits, uint64_t *__restrict__ key, uint32_t *__restrict__ idx) {
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t slot = slot_of(xslot, JI[e]), q = win_of(geom, slot);
-        const uint32_t r = IA[e], bin = r >> RB;
+        const uint32_t slot = slot_of(xslot, JI[e]), qw = win_of(geom, slot);
+        const uint32_t r = IA[e], bin = r >> RB, q = row_class(srcbits, r) * geom.nwin + qw;
         uint32_t sub = 0;
-        if (cutflag[q]) { const uint32_t p = plan[(uint64_t)cutidx[q] * nbins + bin], m = p >> 20; sub = (p & PLAN_SUB_MASK) + (m > 1 ? (slot - win_col0(geom, q)) % m : 0u); }
+        if (cutflag[q]) { const uint32_t p = plan[(uint64_t)cutidx[q] * nbins + bin], m = p >> 20; sub = (p & PLAN_SUB_MASK) + (m > 1 ? (slot - win_col0(geom, qw)) % m : 0u); }
         key[e] = ((((uint64_t)(cbase[q] + sub) << binbits) | bin) << RB) | (r & (R - 1));
         idx[e] = (uint32_t)e;
     }
@@ -295,28 +317,40 @@ __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nru
         cv0[c] = pvstart[a]; cv1[c] = pvstart[b];
     }
 }
-// E[pv] = 1 when the entry at padded v-position pv ends an output. Dense chunks (pv < pv_sparse): the last entry of a maximal
+// per chunk: the pads' defaults. Sparse chunks: every padded position is an output (E = 1) and pads read column 0 of the window;
+// dense chunks: pads read the neutral slot PADCOL and end nothing.
+__global__ void k_chunk_defaults(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1, const uint32_t *__restrict__ ccol0, uint32_t dense_end,
+                                 uint32_t *__restrict__ E, uint16_t *__restrict__ LCOL) {
+    const uint32_t c = blockIdx.x;
+    const bool sparse = ccol0[c] >= dense_end;
+    for (uint32_t pv = cv0[c] + threadIdx.x; pv < cv1[c]; pv += blockDim.x) {
+        if (E) E[pv] = sparse ? 1u : 0u;
+        if (LCOL) LCOL[pv] = sparse ? (uint16_t)0 : PADCOL;
+    }
+}
+// E[pv] = 1 when the entry at padded v-position pv ends an output. Dense chunks: the last entry of a maximal
 // stretch of one row inside one run and inside one aligned block of AGG_MASK + 1 entries. Sparse chunks: every position
-// (pads included, pre-set by the caller) is its own output.
+// (pads included, k_chunk_defaults) is its own output.
 __global__ void k_group_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n,
                              const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart,
-                             uint32_t pv_sparse, uint32_t *__restrict__ E) {
+                             const uint32_t *__restrict__ ccol0, uint32_t dense_end, int chunk_shift, uint32_t *__restrict__ E) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = sid[v] - 1, o = (uint32_t)v - vstart[s], pv = pvstart[s] + o;
+        const bool sparse = ccol0[(uint32_t)(key64[v] >> chunk_shift)] >= dense_end;
         const bool last_of_run = (o + 1 == len[s]);
         const bool last_of_block = ((pv & AGG_MASK) == AGG_MASK);
         const bool row_changes = !last_of_run && ((key64[v + 1] & (R - 1)) != (key64[v] & (R - 1)));
-        E[pv] = (pv >= pv_sparse || last_of_run || last_of_block || row_changes) ? 1u : 0u;
+        E[pv] = (sparse || last_of_run || last_of_block || row_changes) ? 1u : 0u;
     }
 }
 // [pb] stats: how many outputs the DENSE chunks would have if stretches could span 2^k consecutive entries (mask = 2^k - 1)
 __global__ void k_count_ends(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ sid, uint64_t n, const uint32_t *__restrict__ vstart,
-                             const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart, uint32_t pv_sparse, uint32_t mask,
-                             unsigned long long *__restrict__ out) {
+                             const uint32_t *__restrict__ len, const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ ccol0,
+                             uint32_t dense_end, int chunk_shift, uint32_t mask, unsigned long long *__restrict__ out) {
     unsigned long long c = 0;
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = sid[v] - 1, o = (uint32_t)v - vstart[s], pv = pvstart[s] + o;
-        if (pv >= pv_sparse) continue;
+        if (ccol0[(uint32_t)(key64[v] >> chunk_shift)] >= dense_end) continue;
         const bool last_of_run = (o + 1 == len[s]);
         c += (last_of_run || (pv & mask) == mask || ((key64[v + 1] & (R - 1)) != (key64[v] & (R - 1))));
     }
@@ -333,12 +367,12 @@ __global__ void k_static_streams(const uint64_t *__restrict__ key64, const uint3
                                  uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ JI,
                                  const uint32_t *__restrict__ xslot, const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart,
                                  const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ E,
-                                 const uint32_t *__restrict__ X, uint32_t pv_sparse, uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW,
+                                 const uint32_t *__restrict__ X, uint32_t dense_end, uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW,
                                  void *__restrict__ WT, int wt_bytes) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t e = idx[v], c = (uint32_t)(key64[v] >> (RB + binbits)), s = sid[v] - 1, o = (uint32_t)v - vstart[s];
         const uint32_t pv = pvstart[s] + o, ge = E[pv];
-        LCOL[pv] = (uint16_t)((slot_of(xslot, JI[e]) - ccol0[c]) | ((ge && pv < pv_sparse) ? GEND : 0) | (o == 0 ? HEAD : 0));
+        LCOL[pv] = (uint16_t)((slot_of(xslot, JI[e]) - ccol0[c]) | ((ge && ccol0[c] < dense_end) ? GEND : 0) | (o == 0 ? HEAD : 0));
         if (ge) LROW[pkstart[s] + (X[pv] - X[pvstart[s]])] = (uint16_t)(key64[v] & (R - 1));
         if (WT) { if (wt_bytes == 1) ((uint8_t *)WT)[pv] = (uint8_t)A[e]; else if (wt_bytes == 2) ((uint16_t *)WT)[pv] = (uint16_t)A[e]; else ((uint32_t *)WT)[pv] = A[e]; }
     }
@@ -743,7 +777,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
 
 struct gt_pb {
     uint32_t nbins = 0, nchunks = 0, nwork = 0, nnz = 0;
-    uint32_t ndense = 0;       // chunks [0, ndense) belong to dense windows (k_pb_scatter), the rest to sparse ones
+    uint32_t ndense = 0;       // graphs with an exchange layout (one class, K slices): chunks [0, ndense) are dense (all of them)
+    // chunk ranges by (row class, kind): [b[0], b[1]) regular rows / dense windows, [b[1], b[2]) regular / sparse,
+    // [b[2], b[3]) source rows / dense, [b[3], b[4]) source rows / sparse
+    uint32_t bound[5] = {0, 0, 0, 0, 0};
+    uint64_t nnz_source = 0;   // entries of source rows (class 1)
     uint32_t np = 0;           // padded entries of the v-order (multiple of 4)
     uint32_t nout = 0;         // padded outputs of the k-order (multiple of 4): slots of VAL / LROW
     uint32_t *cv0 = nullptr, *cv1 = nullptr, *ccol0 = nullptr;
@@ -881,14 +919,24 @@ int gt_pb_build(gt_graph *g) {
     WinGeom geom;
     geom.ndw = g->ndw; geom.dense_end = g->ndw * W; geom.x_len = g->x_len;
     geom.nwin = g->ndw + (g->x_len > geom.dense_end ? (g->x_len - geom.dense_end + WS - 1) / WS : 0u);
-    const uint32_t nwin = geom.nwin;
+    // row classes: source rows apart (see WinGeom) unless the graph has an exchange layout (K slices of chunks in column order)
+    const bool classes = !gt_has_exchange(g) && nr > 0 && !(getenv("GRAPHTAP_PB_CLASSES") && atoi(getenv("GRAPHTAP_PB_CLASSES")) == 0);
+    geom.ncls = classes ? 2u : 1u; geom.nvwin = geom.nwin * geom.ncls;
+    const uint32_t nwin = geom.nvwin;   // "windows" below are virtual windows: (row class, window)
     (void)nc;
-    uint32_t ch = ch_default(nnz, nwin);
-    DevBuf wcount, nsub, cbase, cutflag, cutidx, plan;
+    uint32_t ch = ch_default(nnz, geom.nwin);
+    DevBuf wcount, nsub, cbase, cutflag, cutidx, plan, srcbits_b;
+    const uint32_t *srcbits = nullptr;
+    if (classes) {
+        PB_ALLOC(srcbits_b, ((uint64_t)nr / 32 + 4) * 4);
+        k_source_bits<<<grid_for(nr), TPB, 0, s>>>(g->R2C, nr, srcbits_b.as<uint32_t>());
+        srcbits = srcbits_b.as<uint32_t>();
+    }
     PB_ALLOC(wcount, (uint64_t)(nwin + 1) * 4); PB_ALLOC(nsub, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cbase, (uint64_t)(nwin + 1) * 4);
     PB_ALLOC(cutflag, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cutidx, (uint64_t)(nwin + 1) * 4);
     PB_HIP(hipMemsetAsync(wcount.p, 0, (uint64_t)(nwin + 1) * 4, s));
     k_win_count<<<grid_for(ncols), TPB, 0, s>>>(g->JA, ncols, g->xslot, geom, wcount.as<uint32_t>());
+    if (classes) k_win_count_src<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, srcbits, wcount.as<uint32_t>());
     uint32_t nchunks = 0;
     for (;;) {  // chunk ids must fit above the bin bits of a 32-bit sort key
         PB_HIP(hipMemsetAsync(nsub.p, 0, (uint64_t)(nwin + 1) * 4, s));
@@ -901,7 +949,7 @@ int gt_pb_build(gt_graph *g) {
         PB_ALLOC(plan, (uint64_t)std::max(ncut, 1u) * pb->nbins * 4);
         if (ncut) {
             PB_HIP(hipMemsetAsync(plan.p, 0, (uint64_t)ncut * pb->nbins * 4, s));
-            k_win_hist<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, pb->nbins, cutflag.as<uint32_t>(), cutidx.as<uint32_t>(), plan.as<uint32_t>());
+            k_win_hist<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, srcbits, pb->nbins, cutflag.as<uint32_t>(), cutidx.as<uint32_t>(), plan.as<uint32_t>());
             k_win_plan<<<grid_for(nwin), TPB, 0, s>>>(wcount.as<uint32_t>(), nwin, ch, pb->nbins, cutflag.as<uint32_t>(), cutidx.as<uint32_t>(),
                                                      plan.as<uint32_t>(), nsub.as<uint32_t>());
         }
@@ -913,7 +961,16 @@ int gt_pb_build(gt_graph *g) {
     int chunkbits = 1;
     while ((1ull << chunkbits) < nchunks) chunkbits++;
     pb->nchunks = nchunks;
-    PB_HIP(hipMemcpy(&pb->ndense, cbase.as<uint32_t>() + std::min(geom.ndw, nwin), 4, hipMemcpyDeviceToHost));   // first chunk of the first sparse window
+    {   // chunk ranges by (row class, kind of window)
+        const uint32_t at[5] = {0, std::min(geom.ndw, geom.nwin), geom.nwin, std::min(geom.nwin + geom.ndw, geom.nvwin), geom.nvwin};
+        for (int i = 0; i < 5; i++) PB_HIP(hipMemcpy(&pb->bound[i], cbase.as<uint32_t>() + std::min(at[i], geom.nvwin), 4, hipMemcpyDeviceToHost));
+        pb->ndense = pb->bound[1];
+        if (classes) {
+            std::vector<uint32_t> hw(geom.nvwin);
+            PB_HIP(hipMemcpy(hw.data(), wcount.p, (uint64_t)geom.nvwin * 4, hipMemcpyDeviceToHost));
+            for (uint32_t q = geom.nwin; q < geom.nvwin; q++) pb->nnz_source += hw[q];
+        }
+    }
     PB_MALLOC(pb->cv0, (uint64_t)nchunks * 4); PB_MALLOC(pb->cv1, (uint64_t)nchunks * 4); PB_MALLOC(pb->ccol0, (uint64_t)nchunks * 4);
     k_fill_chunks<<<grid_for(nwin), TPB, 0, s>>>(nwin, nsub.as<uint32_t>(), cbase.as<uint32_t>(), geom, pb->ccol0);
 
@@ -921,7 +978,7 @@ int gt_pb_build(gt_graph *g) {
     // for equal rows, the column-major input order (ascending compressed column) survives
     DevBuf key, key2, idx, idx2, rkey, sidb;
     PB_ALLOC(key, (uint64_t)nnz * 8); PB_ALLOC(key2, (uint64_t)nnz * 8); PB_ALLOC(idx, (uint64_t)nnz * 4); PB_ALLOC(idx2, (uint64_t)nnz * 4);
-    k_keys<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, cbase.as<uint32_t>(), cutflag.as<uint32_t>(), cutidx.as<uint32_t>(),
+    k_keys<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, srcbits, cbase.as<uint32_t>(), cutflag.as<uint32_t>(), cutidx.as<uint32_t>(),
                                          plan.as<uint32_t>(), pb->nbins, binbits, key.as<uint64_t>(), idx.as<uint32_t>());
     hipcub::DoubleBuffer<uint64_t> dk(key.as<uint64_t>(), key2.as<uint64_t>());
     hipcub::DoubleBuffer<uint32_t> di(idx.as<uint32_t>(), idx2.as<uint32_t>());
@@ -966,25 +1023,27 @@ int gt_pb_build(gt_graph *g) {
     }
     pb->np = np;
     k_chunk_ranges<<<grid_for(nchunks), TPB, 0, s>>>(runkey.as<uint32_t>(), nrun, binbits, pvstart.as<uint32_t>(), nchunks, pb->cv0, pb->cv1);
-    // first padded v-position of the sparse chunks (they follow the dense ones: chunks are numbered window by window)
-    uint32_t pv_sparse = np;
-    if (pb->ndense < nchunks) PB_HIP(hipMemcpy(&pv_sparse, pb->cv0 + pb->ndense, 4, hipMemcpyDeviceToHost));
+    const int chunk_shift = RB + binbits;   // chunk id of a sorted entry = key >> chunk_shift
     const bool stats = getenv("GRAPHTAP_PB_STATS") != nullptr;
     if (stats) {  // entry-weighted histogram of run lengths
         std::vector<uint32_t> hl(nrun);
         PB_HIP(hipMemcpy(hl.data(), len.p, (uint64_t)nrun * 4, hipMemcpyDeviceToHost));
         uint64_t hist[33] = {0}, cnt[33] = {0};
         for (uint32_t l : hl) { int b = 0; while ((1u << (b + 1)) <= l) b++; hist[b] += l; cnt[b]++; }
-        fprintf(stderr, "[pb] nnz=%u padded=%u (+%.2f%%) nbins=%u windows=%u (%u dense) chunks=%u (%u dense) runs=%u mean run=%.1f; sparse entries (padded) %u\n", nnz, np,
-                100.0 * (np - nnz) / nnz, pb->nbins, nwin, geom.ndw, nchunks, pb->ndense, nrun, (double)nnz / nrun, np - pv_sparse);
+        fprintf(stderr, "[pb] nnz=%u padded=%u (+%.2f%%) nbins=%u windows=%u (%u dense) chunks=%u (regular rows: %u dense + %u sparse, source rows: %u + %u) runs=%u mean run=%.1f\n", nnz, np,
+                100.0 * (np - nnz) / nnz, pb->nbins, geom.nwin, geom.ndw, nchunks, pb->bound[1] - pb->bound[0], pb->bound[2] - pb->bound[1],
+                pb->bound[3] - pb->bound[2], pb->bound[4] - pb->bound[3], nrun, (double)nnz / nrun);
+        fprintf(stderr, "[pb] entries of source rows (class 1): %llu of %u (%.2f%%): PageRank under TCSC_CF leaves their chunks out of every iteration but the last\n",
+                (unsigned long long)pb->nnz_source, nnz, 100.0 * pb->nnz_source / nnz);
         for (int b = 0; b < 33; b++) if (cnt[b]) fprintf(stderr, "[pb] run length [%u,%u): %10llu runs, %5.2f%% of entries\n", 1u << b, 1u << (b + 1), (unsigned long long)cnt[b], 100.0 * hist[b] / nnz);
     }
     // outputs: E marks the last entry of each output in the padded v-order, X = exclusive scan of E
     DevBuf Eb, Xb, noutpad;
     PB_ALLOC(Eb, ((uint64_t)np + 1) * 4); PB_ALLOC(Xb, ((uint64_t)np + 1) * 4); PB_ALLOC(noutpad, (uint64_t)(nrun + 1) * 4);
     PB_HIP(hipMemsetAsync(Eb.p, 0, ((uint64_t)np + 1) * 4, s));
-    if (pv_sparse < np) k_fill_t<uint32_t><<<grid_for(np - pv_sparse), TPB, 0, s>>>(Eb.as<uint32_t>() + pv_sparse, np - pv_sparse, 1u);   // sparse: pads are outputs too
-    k_group_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pv_sparse, Eb.as<uint32_t>());
+    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, Eb.as<uint32_t>(), nullptr);   // sparse: pads are outputs too
+    k_group_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pb->ccol0, geom.dense_end,
+                                               chunk_shift, Eb.as<uint32_t>());
     PB_SCAN_EXCL(Eb.as<uint32_t>(), Xb.as<uint32_t>(), (uint64_t)np + 1);
     k_run_outputs<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, noutpad.as<uint32_t>());
     // k-order: runs by (bin, chunk) -- stable sort of the (chunk, bin)-ordered run list by bin
@@ -1008,10 +1067,10 @@ int gt_pb_build(gt_graph *g) {
         k_count_run_rows<<<grid_for(nnz), TPB, 0, s>>>(skey64, nnz, cntb.as<unsigned long long>());
         unsigned long long uq = 0; PB_HIP(hipMemcpy(&uq, cntb.p, 8, hipMemcpyDeviceToHost));
         fprintf(stderr, "[pb] distinct (run,row) groups: %llu of %u entries (factor %.3f)\n", uq, nnz, (double)nnz / uq);
-        fprintf(stderr, "[pb] value-stream slots: %u for %u entries (factor %.3f); dense chunks: %u padded entries\n", nout, nnz, (double)nnz / nout, pv_sparse);
+        fprintf(stderr, "[pb] value-stream slots: %u for %u entries (factor %.3f)\n", nout, nnz, (double)nnz / nout);
         for (uint32_t mask : {7u, 63u, 255u}) {
             DevBuf cb; PB_ALLOC(cb, 8); PB_HIP(hipMemsetAsync(cb.p, 0, 8, s));
-            k_count_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pv_sparse, mask, cb.as<unsigned long long>());
+            k_count_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pb->ccol0, geom.dense_end, chunk_shift, mask, cb.as<unsigned long long>());
             unsigned long long c = 0; PB_HIP(hipMemcpy(&c, cb.p, 8, hipMemcpyDeviceToHost));
             fprintf(stderr, "[pb] dense chunks, stretches of up to %u consecutive entries: %llu outputs\n", mask + 1, c);
         }
@@ -1026,8 +1085,7 @@ int gt_pb_build(gt_graph *g) {
     PB_MALLOC(pb->LCOL, (uint64_t)np * 2); PB_MALLOC(pb->LROW, (uint64_t)std::max(nout, 4u) * 2);
     PB_MALLOC(pb->G, ngroups * sizeof(GroupRec));
     PB_MALLOC(pb->KSTART, (uint64_t)(nrun + 64) * 4);
-    if (pv_sparse) k_fill_t<uint16_t><<<grid_for(pv_sparse), TPB, 0, s>>>(pb->LCOL, pv_sparse, PADCOL);
-    if (pv_sparse < np) PB_HIP(hipMemsetAsync(pb->LCOL + pv_sparse, 0, (uint64_t)(np - pv_sparse) * 2, s));
+    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, nullptr, pb->LCOL);
     k_fill_t<uint16_t><<<grid_for(std::max(nout, 4u)), TPB, 0, s>>>(pb->LROW, std::max(nout, 4u), (uint16_t)R);
     if (g->A) {   // weights travel in the narrowest type that holds the largest one (the reference's converter draws 1..128)
         DevBuf mx; PB_ALLOC(mx, 4); PB_HIP(hipMemsetAsync(mx.p, 0, 4, s));
@@ -1037,7 +1095,7 @@ int gt_pb_build(gt_graph *g) {
         PB_MALLOC(pb->WT, (uint64_t)np * pb->wt_bytes); PB_HIP(hipMemsetAsync(pb->WT, 0, (uint64_t)np * pb->wt_bytes, s));
     }
     k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey64, sidx, sid, nnz, binbits, pb->ccol0, g->JI, g->xslot, g->A, vstart.as<uint32_t>(),
-                                                   pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Eb.as<uint32_t>(), Xb.as<uint32_t>(), pv_sparse,
+                                                   pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Eb.as<uint32_t>(), Xb.as<uint32_t>(), geom.dense_end,
                                                    pb->LCOL, pb->LROW, pb->WT, pb->wt_bytes);
     k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
     PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nrun + 64) * 4, s));
@@ -1097,13 +1155,11 @@ int gt_pb_build(gt_graph *g) {
         PB_HIP(hipMemcpy(a.data(), pb->cv0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
         PB_HIP(hipMemcpy(b.data(), pb->cv1, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < nchunks; c++) ord[c] = c;
-        if (!getenv("GRAPHTAP_PB_COLUMN_ORDER"))
-            for (uint32_t k = 0; k < K; k++) {
-                const uint32_t lo = pb->slice_chunk[k], hi = pb->slice_chunk[k + 1], mid = std::min(std::max(pb->ndense, lo), hi);
-                auto bigger = [&](uint32_t x, uint32_t y) { return b[x] - a[x] > b[y] - a[y]; };
-                std::stable_sort(ord.begin() + lo, ord.begin() + mid, bigger);
-                std::stable_sort(ord.begin() + mid, ord.begin() + hi, bigger);
-            }
+        if (!getenv("GRAPHTAP_PB_COLUMN_ORDER")) {
+            auto bigger = [&](uint32_t x, uint32_t y) { return b[x] - a[x] > b[y] - a[y]; };
+            if (K == 1) for (int i = 0; i < 4; i++) std::stable_sort(ord.begin() + pb->bound[i], ord.begin() + pb->bound[i + 1], bigger);
+            else for (uint32_t k = 0; k < K; k++) std::stable_sort(ord.begin() + pb->slice_chunk[k], ord.begin() + pb->slice_chunk[k + 1], bigger);   // one class, all dense
+        }
         PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
         PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
     }
@@ -1115,7 +1171,7 @@ int gt_pb_build(gt_graph *g) {
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy = uint32_t>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
-                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {
+                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see stage_window).
     const bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
     if (phases & GT_PB_PREPARE) {
@@ -1127,19 +1183,29 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         }
     }
     if (phases & GT_PB_PHASE1) {
-        const uint32_t c0 = pb->slice_chunk[slice_lo], c1 = pb->slice_chunk[slice_hi];
-        const uint32_t mid = std::min(std::max(pb->ndense, c0), c1);   // [c0, mid) dense, [mid, c1) sparse
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
-        // the sparse chunks go first: they are the uniform ones, the dense launch (largest chunks first) follows. (Side by side
-        // on two streams the two kernels took 2.9 + 3.1 ms instead of 0.3 + 1.7: they fight for the same LDS.)
-        if (c1 > mid)
-            k_pb_scatter_sparse<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - mid, P1_THREADS, 0, s>>>(
-                pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, mid);
-        if (mid > c0)
-            k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<mid - c0, P1_THREADS, 0, s>>>(
-                pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0);
+        auto dense = [&](uint32_t c0, uint32_t c1) {
+            if (c1 > c0)
+                k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
+                    pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
+                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0);
+        };
+        auto sparse = [&](uint32_t c0, uint32_t c1) {
+            if (c1 > c0)
+                k_pb_scatter_sparse<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
+                    pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
+                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0);
+        };
+        if (g->info.x_slices == 1) {
+            // the sparse chunks go first: they are the uniform ones, the dense launch (largest chunks first) follows. (Side by side
+            // on two streams the two kernels took 2.9 + 3.1 ms instead of 0.3 + 1.7: they fight for the same LDS.)
+            sparse(pb->bound[1], pb->bound[2]);
+            dense(pb->bound[0], pb->bound[1]);
+            if (!skip_source) {   // computation filtering (TCSC_CF): the entries of source rows only count on the last iteration
+                sparse(pb->bound[3], pb->bound[4]);
+                dense(pb->bound[2], pb->bound[3]);
+            }
+        } else dense(pb->slice_chunk[slice_lo], pb->slice_chunk[slice_hi]);   // exchange layout: identity x, every window dense
     }
     if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
@@ -1161,9 +1227,10 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
 
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
 uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
+uint64_t gt_pb_source_entries(const gt_graph *g) { return g->pb ? g->pb->nnz_source : 0; }
 
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi) {
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -1184,16 +1251,16 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr, false);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
-            if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr);
+            if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
+            if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

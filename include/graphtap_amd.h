@@ -152,6 +152,9 @@ typedef struct gt_exec_stats {
     /* sums of squares (ms^2) of the per-iteration phase times, for the reference's "sum: avg +/- std_dev" record
      * (stats(), vp:2183-2190); like the sums only meaningful with GRAPHTAP_TIMING=1 */
     double scatter_gather_sq, combine_sq, apply_sq;
+    uint32_t cf_filtered_iterations; /* PageRank under GT_TCSC_CF: SpMVs that left the entries of source rows out (computation
+                                        filtering, compressed_column.hpp:671-708, vp:1264-1317: all but the last iteration) */
+    uint32_t reserved_;
 } gt_exec_stats;
 
 /* state fields for gt_program_copy_state */

@@ -79,7 +79,7 @@ def test_deg_checksum1_and_timing_record():
     assert "Sum: mean +/- std_dev: 16384.000000: 15.984390 +/- 81.271468" in r.stdout
     assert "Mode & skew : 0 & 0.196679" in r.stdout
     assert "Max index : 613" in r.stdout and "Max value : 1983" in r.stdout
-    assert "TIMING scatter_gather" in r.stdout
+    assert "Combine        time (sum: avg +/- std_dev):" in r.stdout and "\nTIMING " in r.stdout   # format pinned by the test below
 
 
 # ------------------------------------------------------------------------------- edge-list converter (host only)

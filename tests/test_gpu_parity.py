@@ -226,6 +226,30 @@ def test_bfs_sssp_cc_bit_exact(gt, name, known_answers):
     assert (r["iterations"], r["checksum"]) == (ka["iterations"], (ka["checksum"], ka["reachable"]))
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_tcsc_cf_computation_filtering(gt, name, known_answers, monkeypatch):
+    """TCSC_CF's computation filtering (compressed_column.hpp:671-708, vp:1264-1317): the entries of SOURCE rows (vertices
+    with in-edges but no out-edges) are left out of every SpMV but the last one -- never in converge mode, where the
+    reference's source rows end at exactly alpha (SURVEY trap 5). Here they live in chunks of their own that PageRank under
+    GT_TCSC_CF does not launch until the last iteration: the golden vectors must come out with the filtering on (default)
+    and off, and the statistics must say that it happened."""
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("GRAPHTAP_NO_CF_FILTER", env)
+        r = run_pr(gt, c["edges"], nv, 20, cf=True)
+        ref = c["np1_pr20_c"]
+        assert (np.abs(r["rank"][:n] - ref) / ref).max() < PR_RTOL and (r["degree"][:n] == c["np1_pr20_a"]).all()
+        assert r["stats"].cf_filtered_iterations == (0 if env else 19)
+        r = run_pr(gt, c["edges"], nv, 0, cf=True)
+        ref = c["np1_prconv_cf_c"]
+        assert r["iterations"] == known_answers[name]["np1_prconv_cf"]["iterations"]
+        assert (np.abs(r["rank"][:n] - ref) / ref).max() < PR_RTOL
+        assert r["stats"].cf_filtered_iterations == (0 if env else r["iterations"])
+    monkeypatch.delenv("GRAPHTAP_NO_CF_FILTER")
+    r = run_pr(gt, c["edges"], nv, 20, cf=False)      # plain TCSC (apps/pr1.cpp): nothing is filtered
+    assert r["stats"].cf_filtered_iterations == 0
+
+
 @pytest.mark.parametrize("mode", ["1", "0"])
 @pytest.mark.parametrize("name", CASES)
 def test_sparse_frontier_spmspv_is_bit_exact(gt, name, mode, known_answers, monkeypatch):
