@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgraphtap_amd.so")
+LIB_PATH = os.environ.get("GRAPHTAP_LIB") or os.path.join(HERE, "lib", "libgraphtap_amd.so")   # GRAPHTAP_LIB: an alternative build (A/B experiments)
 
 GT_INF = 2147483647
 GT_DEG, GT_PR, GT_BFS, GT_SSSP, GT_CC = range(5)

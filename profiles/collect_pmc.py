@@ -36,13 +36,14 @@ def per_kernel(d, counter):
 
 def main():
     fetch_dir, write_dir, key = sys.argv[1:4]
+    out_path = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     spmv = [k for k in fetch if k.startswith("k_pb_") or k.startswith("k_spmv_edge")]
     rec = {"kernels": {k: {"hbm_read_bytes": 2 * fetch[k], "hbm_write_bytes": write.get(k, 0.0)} for k in sorted(fetch)
                        if k.startswith(("k_pb_", "k_spmv_edge", "k_pr_", "k_msg_", "k_apply_"))},
            "hbm_bytes_per_launch": sum(2 * fetch[k] + write.get(k, 0.0) for k in spmv),
-           "note": "one SpMV launch = the k_pb_scatter + k_pb_gather pair; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes"}
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+           "note": "one SpMV launch = k_pb_scatter_sparse + k_pb_scatter + k_pb_gather; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes"}
+    out = out_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     allrec = json.load(open(out)) if os.path.exists(out) else {}
     allrec[key] = rec
     json.dump(allrec, open(out, "w"), indent=1, sort_keys=True)
