@@ -13,7 +13,7 @@
 //                     combines its quad in registers, lanes meet through LDS atomics on the wave's staging row -- and
 //                     the (value, slot) pairs of a group are stored as coalesced runs (k_pb_scatter);
 //              SPARSE windows (WS = 16384 slots, low-degree columns, nothing to aggregate): one slot per entry, the
-//                     slot is the entry's position: four values per lane stored with one 16-byte store (k_pb_scatter_sparse).
+//                     slot is the entry's position: four values per lane stored with one 16-byte store (same kernel, other branch).
 //   phase 2  "gather"    one workgroup per ROW BIN (R = 16384 consecutive compressed rows; heavy
 //            bins are split by slot count): the bin's partial accumulators live in LDS (R x 8 B =
 //            128 KiB for f64), the bin's slice of VAL and of the static bin-local row ids LROW is
@@ -470,7 +470,7 @@ __device__ __forceinline__ bool stage_window(TV *__restrict__ xwin, const TX *__
     constexpr int PER = (WIN + THREADS - 1) / THREADS;
     TX t[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * THREADS; t[i] = (j < wn) ? x[col0 + j] : TX(0); }
+    for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * THREADS; t[i] = (j < wn) ? x[col0 + j] : (IS_MIN ? (TX)GT_INF : TX(0)); }   // beyond the window: the neutral message (slot W of a dense window is what pad entries read)
 #pragma unroll
     for (int i = 0; i < PER; i++) { const uint32_t j = threadIdx.x + i * THREADS; if (j < WIN) xwin[j] = (TV)t[i]; }
     if constexpr (IS_MIN) {
@@ -574,16 +574,20 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
-                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0) {
-    __shared__ TV xwin[W + 1];
+                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end) {
+    static_assert(W + 1 == WS, "dense and sparse chunks share one LDS window");
+    __shared__ TV xwin[WS];
     const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)
-    const uint32_t wn = (ncols - col0 < W) ? ncols - col0 : W;
+    // ONE launch for both kinds of chunks (dense ones first, largest first; the light sparse ones fill the tail): two launches
+    // cost a drain of the 64-KiB workgroups in between
+    const bool sparse = col0 >= dense_end;
+    const uint32_t wlim = sparse ? WS : W;
+    const uint32_t wn = (ncols - col0 < wlim) ? ncols - col0 : wlim;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) xwin[PADCOL] = neutral;
-    if (!stage_window<TV, TX, IS_MIN, P1_THREADS, W>(xwin, x, col0, wn, chunk_active, c)) return;
+    if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
     __syncthreads();
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 4;   // 256-entry groups in flight per wave
@@ -611,6 +615,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (g0 + u >= gend) break;
+            if (sparse) {   // one output per entry, its k-slot is its position: four values per lane, one 16-byte store
+                const uint32_t delta = run_delta(lane, lane != 0 && (lc[u].c[0] & HEAD) != 0, gw[u], KSTART);
+                V4<TV> o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) o.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & COLMASK], w[u].w[j]);
+                *reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)) = o;   // runs start at multiples of four slots in both orders
+                continue;
+            }
             // output-end bits of the quad
             const bool e0 = (lc[u].c[0] & GEND) != 0, e1 = (lc[u].c[1] & GEND) != 0, e2 = (lc[u].c[2] & GEND) != 0, e3 = (lc[u].c[3] & GEND) != 0;
             const uint32_t n0 = e0 ? 1u : 0u, n1 = n0 + (e1 ? 1u : 0u), n2 = n1 + (e2 ? 1u : 0u), nend = n2 + (e3 ? 1u : 0u);
@@ -638,57 +650,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     }
 }
 
-// ---- sparse windows: one output per entry, its k-slot is its position; four values per lane, one 16-byte store
-template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy>
-__global__ void __launch_bounds__(P1_THREADS) k_pb_scatter_sparse(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
-                                                                  const uint32_t *__restrict__ ccol0, uint32_t ncols,
-                                                                  const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
-                                                                  const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
-                                                                  const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
-                                                                  const uint32_t *__restrict__ launch_order, uint32_t chunk0) {
-    __shared__ TV xwin[WS];
-    const uint32_t c = launch_order[chunk0 + blockIdx.x];
-    const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];
-    const uint32_t wn = (ncols - col0 < WS) ? ncols - col0 : WS;
-    if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr uint32_t NW = P1_THREADS / 64;
-    constexpr int U = 4;
-    const uint32_t gend = q1c >> 6;
-    const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
-    C4 lc[U], nlc[U]; uint32_t gw[U], ngw[U]; WQ<WTy> w[U], nw[U];
-    auto issue_loads = [&](uint32_t g0, C4 (&olc)[U], uint32_t (&ogw)[U], WQ<WTy> (&ow)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
-            const uint32_t q = g * 64 + lane;
-            olc[u] = LCOL4[q];
-            ogw[u] = Gw[(uint64_t)g * 8 + (lane & 7)];
-            if constexpr (WEIGHTED) ow[u] = WT4[q]; else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
-        }
-    };
-    uint32_t g0 = (q0c >> 6) + wave * U;
-    if (g0 < gend) issue_loads(g0, lc, gw, w);
-    while (g0 < gend) {
-        const uint32_t gn = g0 + NW * U;
-        if (gn < gend) issue_loads(gn, nlc, ngw, nw);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (g0 + u >= gend) break;
-            const uint32_t delta = run_delta(lane, lane != 0 && (lc[u].c[0] & HEAD) != 0, gw[u], KSTART);
-            V4<TV> o;
-#pragma unroll
-            for (int j = 0; j < 4; j++) o.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & COLMASK], w[u].w[j]);
-            *reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)) = o;   // runs start at multiples of four slots in both orders
-        }
-        g0 = gn;
-#pragma unroll
-        for (int u = 0; u < U; u++) { lc[u] = nlc[u]; gw[u] = ngw[u]; w[u] = nw[u]; }
-    }
-}
-
+// ------------------------------------------------------------------ phase 2
 template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *acc, uint32_t r, T a) {
     if constexpr (IS_MIN) { if (a != GT_INF) atomicMin(&acc[r], a); }
     else if constexpr (sizeof(T) == 8) unsafeAtomicAdd(&acc[r], a);   // ds_add_f64
@@ -733,17 +695,34 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
             using TX = typename std::conditional<FUSE == 1, float, double>::type;
             TX *__restrict__ xo = (TX *)epi.x;
             unsigned act = 0;
-            for (uint32_t i = threadIdx.x; i < rn; i += P2_THREADS) {
-                const uint32_t r = row0 + i, c = epi.R2X[r];
-                const bool source = (c == 0xFFFFFFFFu);
-                if (epi.cf && source && !epi.last) continue;   // vp:1671-1691
-                const double tmp = epi.rank_c[r];
-                const double nv = epi.alpha + (1.0 - epi.alpha) * (double)acc[i];
-                epi.rank_c[r] = nv;
-                const uint8_t ch = fabs(nv - tmp) > epi.tol;
-                epi.C_c[r] = ch;
-                act += (ch && !(epi.cf && source));
-                if (!source) { const uint32_t d = epi.deg_c[r]; xo[c] = (TX)(d ? nv / (double)d : 0.0); }
+            // EB rows per thread and trip, every load of the trip issued before the first store: the flush of a 16 384-row bin is
+            // 16 dependent round trips per thread otherwise (latency-bound for ~30 % of the workgroup's life)
+#ifndef GT_P2_EB
+#define GT_P2_EB 8
+#endif
+            constexpr int EB = GT_P2_EB;
+            for (uint32_t i0 = threadIdx.x; i0 < rn; i0 += EB * P2_THREADS) {
+                uint32_t c[EB], d[EB]; double tmp[EB]; bool live[EB];
+#pragma unroll
+                for (int u = 0; u < EB; u++) {
+                    const uint32_t i = i0 + u * P2_THREADS, r = row0 + i;
+                    live[u] = i < rn;
+                    c[u] = live[u] ? epi.R2X[r] : 0xFFFFFFFFu;
+                    tmp[u] = live[u] ? epi.rank_c[r] : 0.0;
+                    d[u] = live[u] ? epi.deg_c[r] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < EB; u++) {
+                    const uint32_t i = i0 + u * P2_THREADS, r = row0 + i;
+                    const bool source = (c[u] == 0xFFFFFFFFu);
+                    if (!live[u] || (epi.cf && source && !epi.last)) continue;   // vp:1671-1691
+                    const double nv = epi.alpha + (1.0 - epi.alpha) * (double)acc[i];
+                    epi.rank_c[r] = nv;
+                    const uint8_t ch = fabs(nv - tmp[u]) > epi.tol;
+                    epi.C_c[r] = ch;
+                    act += (ch && !(epi.cf && source));
+                    if (!source) xo[c[u]] = (TX)(d[u] ? nv / (double)d[u] : 0.0);
+                }
             }
             if (epi.d_active) {   // one atomic per workgroup
                 __shared__ unsigned wsum[P2_THREADS / 64];
@@ -1136,6 +1115,10 @@ int gt_pb_build(gt_graph *g) {
         PB_HIP(hipMemcpy(pb->bin_single, single.data(), pb->nbins, hipMemcpyHostToDevice));
         if (stats) fprintf(stderr, "[pb] phase 2: %u workgroups for %u bins, %u of %u rows in single-workgroup bins\n", pb->nwork, pb->nbins, pb->rows_single, nr);
     }
+    // largest first: the workgroups of a launch are dispatched in order and one fits per CU (128 KiB of LDS), so the
+    // heavy (hub) bins must not end up in the last of the ~7 rounds
+    if (!getenv("GRAPHTAP_PB_BIN_ORDER"))
+        std::stable_sort(work.begin(), work.end(), [](const BinWork &a, const BinWork &b) { return a.k1 - a.k0 > b.k1 - b.k0; });
     PB_MALLOC(pb->work, work.size() * sizeof(BinWork));
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
     if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
@@ -1184,28 +1167,16 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     }
     if (phases & GT_PB_PHASE1) {
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
-        auto dense = [&](uint32_t c0, uint32_t c1) {
+        auto scatter = [&](uint32_t c0, uint32_t c1) {
             if (c1 > c0)
                 k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
                     pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0);
+                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W);
         };
-        auto sparse = [&](uint32_t c0, uint32_t c1) {
-            if (c1 > c0)
-                k_pb_scatter_sparse<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
-                    pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0);
-        };
-        if (g->info.x_slices == 1) {
-            // the sparse chunks go first: they are the uniform ones, the dense launch (largest chunks first) follows. (Side by side
-            // on two streams the two kernels took 2.9 + 3.1 ms instead of 0.3 + 1.7: they fight for the same LDS.)
-            sparse(pb->bound[1], pb->bound[2]);
-            dense(pb->bound[0], pb->bound[1]);
-            if (!skip_source) {   // computation filtering (TCSC_CF): the entries of source rows only count on the last iteration
-                sparse(pb->bound[3], pb->bound[4]);
-                dense(pb->bound[2], pb->bound[3]);
-            }
-        } else dense(pb->slice_chunk[slice_lo], pb->slice_chunk[slice_hi]);   // exchange layout: identity x, every window dense
+        // one launch: [regular rows: dense, sparse][source rows: dense, sparse]; computation filtering (TCSC_CF) leaves the
+        // source rows' chunks out of every iteration but the last
+        if (g->info.x_slices == 1) scatter(pb->bound[0], skip_source ? pb->bound[2] : pb->bound[4]);
+        else scatter(pb->slice_chunk[slice_lo], pb->slice_chunk[slice_hi]);   // exchange layout: identity x, every window dense
     }
     if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
