@@ -99,6 +99,7 @@ SIGNATURES = {
     "gt_dist_free": (C.c_int, [_vp]),
     "gt_dist_execute": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(ExecStats)]),
     "gt_dist_all_reduce_u64": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_uint32]),
+    "gt_dist_exchange_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "gt_spmv": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "gt_rmat_generate": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, _vp]),
     "gt_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),

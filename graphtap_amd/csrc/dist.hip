@@ -74,8 +74,48 @@ __global__ void k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
 
+// ---- sparse frontier exchange (min programs): blocks of the send buffer with few active (!= infinity()) messages travel as
+// (index in block, value) pairs -- the reference's sparse broadcast, vp:970-1013, with its 0 = dense / k = k-1 entries count
+// header (vp:766-773) replaced by a count exchange
+struct BlockTab { uint32_t start, len; };   // a (slice, peer) block of the send buffer / of x
+__device__ __forceinline__ uint32_t block_of(const BlockTab *__restrict__ tab, uint32_t nb, uint32_t i) {
+    uint32_t lo = 0, hi = nb;   // last block whose start <= i (blocks are in ascending order, empty ones included)
+    while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (tab[mid].start <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_block_active(const uint32_t *__restrict__ send, uint32_t n, const BlockTab *__restrict__ tab, uint32_t nb, uint32_t *__restrict__ counts) {
+    const uint32_t n64 = (n + 63) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += gridDim.x * blockDim.x) {
+        const bool act = i < n && send[i] != GT_INF;
+        const uint32_t b = i < n ? block_of(tab, nb, i) : 0xFFFFFFFFu;
+        const uint32_t b0 = __builtin_amdgcn_readfirstlane(b);
+        if (__all(b == b0 || i >= n)) {   // a wave rarely straddles blocks
+            const uint64_t m = __ballot(act);
+            if ((threadIdx.x & 63) == 0 && m && b0 != 0xFFFFFFFFu) atomicAdd(&counts[b0], (uint32_t)__popcll((unsigned long long)m));
+        } else if (act) atomicAdd(&counts[b], 1u);
+    }
+}
+// pairs of block b go to pairs[tab[b].start ...] (a sparse block holds at most len / 2 of them)
+__global__ void k_block_compact(const uint32_t *__restrict__ send, uint32_t n, const BlockTab *__restrict__ tab, uint32_t nb, const uint8_t *__restrict__ sparse,
+                                uint32_t *__restrict__ cursor, uint2 *__restrict__ pairs) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = send[i];
+        if (v == GT_INF) continue;
+        const uint32_t b = block_of(tab, nb, i);
+        if (!sparse[b]) continue;
+        pairs[tab[b].start + atomicAdd(&cursor[b], 1u)] = uint2{i - tab[b].start, v};
+    }
+}
+__global__ void k_fill_u32(uint32_t *__restrict__ p, uint32_t n, uint32_t v) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_scatter_pairs(const uint2 *__restrict__ pairs, uint32_t n, uint32_t *__restrict__ xblock) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint2 pv = pairs[i]; xblock[pv.x] = pv.y; }
+}
+
 // ---- loopback: what the p ranks of one process share
-struct LoopPeer { const char *send = nullptr; const uint32_t *y = nullptr; const gt_graph *g = nullptr; uint32_t x_bytes = 0; uint64_t word = 0; };
+struct LoopPeer { const char *send = nullptr; const uint32_t *y = nullptr; const gt_graph *g = nullptr; uint32_t x_bytes = 0; uint64_t word = 0;
+                  const uint2 *pairs = nullptr; const uint32_t *counts = nullptr; /* host [K*P] active messages per send block, or null = all dense */ };
 struct LoopCtx {
     int n = 0;
     std::mutex mu;
@@ -105,6 +145,18 @@ struct gt_dist {
     // loopback
     std::shared_ptr<LoopCtx> loop;
     uint32_t *tmp = nullptr; uint64_t tmp_elems = 0;
+    // sparse frontier exchange: block tables of the current graph, counts, pair buffers
+    const gt_graph *sp_graph = nullptr;
+    BlockTab *d_stab = nullptr;                      // [K*P] send blocks
+    uint32_t *d_cnt = nullptr, *d_cur = nullptr;     // [K*P] active messages / compaction cursors per send block
+    uint8_t *d_smode = nullptr;                      // [K*P] 1 = the send block travels as pairs
+    uint32_t *d_cx = nullptr;                        // [2][P*K] count exchange staging (RCCL)
+    uint2 *pairs_send = nullptr, *pairs_recv = nullptr;
+    uint64_t pairs_send_cap = 0, pairs_recv_cap = 0;
+    std::vector<BlockTab> stab, rtab;                // host copies: send blocks, blocks of x
+    std::vector<uint32_t> cnt_send, cnt_recv;        // [K*P] this iteration: what I send / what each peer sends me
+    bool sparse_now = false;                         // this iteration's exchange uses the counts above
+    uint64_t bytes_sent = 0, bytes_dense = 0, exchanges = 0;   // since the last gt_dist_exchange_stats reset (sent: to other ranks and to itself)
 };
 
 namespace {
@@ -130,12 +182,88 @@ int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s
     return GT_OK;
 }
 
+static inline bool block_sparse(uint32_t count, uint32_t len) { return len != 0 && 2ull * count < len; }   // pairs cost 8 B, a dense message 4
+
+// min programs: counts the active messages of every send block, tells every peer, compacts the sparse blocks into pairs
+int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
+    d->sparse_now = false;
+    const gt_graph *g = p->g;
+    const char *env = getenv("GRAPHTAP_SPARSE_EXCHANGE");
+    if (p->stationary || p->x_bytes != 4 || (env && atoi(env) == 0)) return GT_OK;   // (the same decision on every rank)
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, NB = K * P;
+    if (d->sp_graph != g) {   // block tables of this graph
+        d->stab.assign(NB, BlockTab{0, 0}); d->rtab.assign(NB, BlockTab{0, 0});
+        for (uint32_t k = 0; k < K; k++) {
+            uint64_t so = g->send_off[k], ro = g->recv_off[k];
+            for (uint32_t q = 0; q < P; q++) {
+                d->stab[k * P + q] = BlockTab{(uint32_t)so, g->send_counts[(size_t)k * P + q]};
+                d->rtab[k * P + q] = BlockTab{(uint32_t)ro, g->recv_counts[(size_t)k * P + q]};
+                so += g->send_counts[(size_t)k * P + q]; ro += g->recv_counts[(size_t)k * P + q];
+            }
+        }
+        for (void *q : {(void *)d->d_stab, (void *)d->d_cnt, (void *)d->d_cur, (void *)d->d_smode, (void *)d->d_cx}) if (q) GT_HIP(hipFree(q));
+        GT_HIP(hipMalloc((void **)&d->d_stab, NB * sizeof(BlockTab))); GT_HIP(hipMalloc((void **)&d->d_cnt, NB * 4)); GT_HIP(hipMalloc((void **)&d->d_cur, NB * 4));
+        GT_HIP(hipMalloc((void **)&d->d_smode, NB)); GT_HIP(hipMalloc((void **)&d->d_cx, 2ull * NB * 4));
+        GT_HIP(hipMemcpy(d->d_stab, d->stab.data(), NB * sizeof(BlockTab), hipMemcpyHostToDevice));
+        if (d->pairs_send_cap < std::max<uint64_t>(g->send_elems, 1)) { if (d->pairs_send) GT_HIP(hipFree(d->pairs_send)); d->pairs_send = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_send, std::max<uint64_t>(g->send_elems, 1) * 8)); d->pairs_send_cap = std::max<uint64_t>(g->send_elems, 1); }
+        if (d->pairs_recv_cap < std::max<uint32_t>(g->ncols_total, 1)) { if (d->pairs_recv) GT_HIP(hipFree(d->pairs_recv)); d->pairs_recv = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_recv, (uint64_t)std::max<uint32_t>(g->ncols_total, 1) * 8)); d->pairs_recv_cap = std::max<uint32_t>(g->ncols_total, 1); }
+        d->cnt_send.assign(NB, 0); d->cnt_recv.assign(NB, 0);
+        d->sp_graph = g;
+    }
+    const uint32_t n = (uint32_t)g->send_elems;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096));
+    GT_HIP(hipMemsetAsync(d->d_cnt, 0, NB * 4, s));
+    k_block_active<<<grid, 256, 0, s>>>((const uint32_t *)p->send, n, d->d_stab, NB, d->d_cnt);
+    GT_HIP(hipMemcpyAsync(d->cnt_send.data(), d->d_cnt, NB * 4, hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    // every peer learns how many active messages each of its blocks from me holds (and so which form they take)
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        c.peer[d->rank].counts = d->cnt_send.data();
+        c.barrier();
+        for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) d->cnt_recv[k * P + q] = c.peer[q].counts[k * P + d->rank];
+        c.barrier();
+    } else {
+        std::vector<uint32_t> out(NB), in(NB);   // [peer][slice]
+        for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) out[q * K + k] = d->cnt_send[k * P + q];
+        GT_HIP(hipMemcpyAsync(d->d_cx, out.data(), NB * 4, hipMemcpyHostToDevice, s));
+        GT_NCCL(rccl()->GroupStart());
+        for (uint32_t q = 0; q < P; q++) {
+            GT_NCCL(rccl()->Send(d->d_cx + q * K, K, ncclUint32, (int)q, d->comm, s));
+            GT_NCCL(rccl()->Recv(d->d_cx + NB + q * K, K, ncclUint32, (int)q, d->comm, s));
+        }
+        GT_NCCL(rccl()->GroupEnd());
+        GT_HIP(hipMemcpyAsync(in.data(), d->d_cx + NB, NB * 4, hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) d->cnt_recv[k * P + q] = in[q * K + k];
+    }
+    std::vector<uint8_t> mode(NB);
+    bool any = false;
+    for (uint32_t b = 0; b < NB; b++) { mode[b] = block_sparse(d->cnt_send[b], d->stab[b].len); any |= mode[b] != 0; }
+    if (any) {
+        GT_HIP(hipMemcpyAsync(d->d_smode, mode.data(), NB, hipMemcpyHostToDevice, s));
+        GT_HIP(hipMemsetAsync(d->d_cur, 0, NB * 4, s));
+        k_block_compact<<<grid, 256, 0, s>>>((const uint32_t *)p->send, n, d->d_stab, NB, d->d_smode, d->d_cur, d->pairs_send);
+        GT_HIP(hipStreamSynchronize(s));   // `mode` is a host buffer
+    }
+    // the sparse blocks of x start from infinity(): only their active messages arrive
+    for (uint32_t b = 0; b < NB; b++)
+        if (block_sparse(d->cnt_recv[b], d->rtab[b].len)) k_fill_u32<<<(d->rtab[b].len + 255) / 256, 256, 0, s>>>((uint32_t *)p->x + d->rtab[b].start, d->rtab[b].len, GT_INF);
+    GT_HIP(hipGetLastError());
+    d->sparse_now = true;
+    return GT_OK;
+}
+
 // the K slices of one iteration's exchange are ISSUED here (all of them); consume(k) then makes `s` wait for slice k
 int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
     const gt_graph *g = p->g;
     const uint32_t K = g->info.x_slices, P = g->info.nranks, w = p->x_bytes;
+    { int st = sparse_prepare(d, p, s); if (st != GT_OK) return st; }
+    const bool sp = d->sparse_now;
+    d->exchanges++;
     if (d->loop) {
         LoopCtx &c = *d->loop;
+        c.peer[d->rank].pairs = d->pairs_send;
         GT_HIP(hipStreamSynchronize(s));                      // my send buffer is packed
         c.barrier();
         for (uint32_t k = 0; k < K; k++) {
@@ -146,9 +274,16 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
                 for (uint32_t q = 0; q < (uint32_t)d->rank; q++) off += gs->send_counts[(size_t)k * P + q];
                 const uint32_t n = g->recv_counts[(size_t)k * P + src];
                 GT_REQUIRE(n == gs->send_counts[(size_t)k * P + d->rank], GT_ERR_STATE, "exchange plan mismatch between ranks %u and %d (slice %u)", src, d->rank, k);
-                if (n) GT_HIP(hipMemcpyAsync((char *)p->x + dst * w, c.peer[src].send + off * w, (uint64_t)n * w, hipMemcpyDeviceToDevice, s));
+                const uint32_t cnt = sp ? d->cnt_recv[k * P + src] : 0;
+                if (sp && block_sparse(cnt, n)) {
+                    if (cnt) GT_HIP(hipMemcpyAsync(d->pairs_recv + dst, c.peer[src].pairs + off, (uint64_t)cnt * 8, hipMemcpyDeviceToDevice, s));
+                } else if (n) GT_HIP(hipMemcpyAsync((char *)p->x + dst * w, c.peer[src].send + off * w, (uint64_t)n * w, hipMemcpyDeviceToDevice, s));
                 dst += n;
             }
+        }
+        for (uint32_t b = 0; b < K * P; b++) {   // what this rank SENDS (the mirror image of the copies above)
+            const uint32_t len = g->send_counts[b], cnt = sp ? d->cnt_send[b] : 0;
+            d->bytes_dense += (uint64_t)len * w; d->bytes_sent += (sp && block_sparse(cnt, len)) ? (uint64_t)cnt * 8 : (uint64_t)len * w;
         }
         GT_HIP(hipStreamSynchronize(s));
         c.barrier();                                          // every rank has read every send buffer
@@ -163,8 +298,12 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
         GT_NCCL(rccl()->GroupStart());
         for (uint32_t q = 0; q < P; q++) {
             const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
-            if (ns) GT_NCCL(rccl()->Send((const char *)p->send + so * w, ns, ty, (int)q, d->comm, d->comm_stream));
-            if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
+            const uint32_t cs = sp ? d->cnt_send[k * P + q] : 0, cr = sp ? d->cnt_recv[k * P + q] : 0;
+            d->bytes_dense += (uint64_t)ns * w;
+            if (sp && block_sparse(cs, ns)) { if (cs) GT_NCCL(rccl()->Send(d->pairs_send + so, 2ull * cs, ncclUint32, (int)q, d->comm, d->comm_stream)); d->bytes_sent += 8ull * cs; }
+            else if (ns) { GT_NCCL(rccl()->Send((const char *)p->send + so * w, ns, ty, (int)q, d->comm, d->comm_stream)); d->bytes_sent += (uint64_t)ns * w; }
+            if (sp && block_sparse(cr, nr)) { if (cr) GT_NCCL(rccl()->Recv(d->pairs_recv + ro, 2ull * cr, ncclUint32, (int)q, d->comm, d->comm_stream)); }
+            else if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
             so += ns; ro += nr;
         }
         GT_NCCL(rccl()->GroupEnd());
@@ -172,8 +311,17 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
     }
     return GT_OK;
 }
-int exchange_consume(gt_dist *d, uint32_t k, hipStream_t s) {
+int exchange_consume(gt_dist *d, gt_program *p, uint32_t k, hipStream_t s) {
     if (!d->loop) GT_HIP(hipStreamWaitEvent(s, d->ev_slice[k], 0));
+    if (d->sparse_now) {   // the pairs of slice k's sparse blocks land in x
+        const uint32_t P = p->g->info.nranks;
+        for (uint32_t q = 0; q < P; q++) {
+            const BlockTab t = d->rtab[k * P + q];
+            const uint32_t cnt = d->cnt_recv[k * P + q];
+            if (block_sparse(cnt, t.len) && cnt) k_scatter_pairs<<<(cnt + 255) / 256, 256, 0, s>>>(d->pairs_recv + t.start, cnt, (uint32_t *)p->x + t.start);
+        }
+        GT_HIP(hipGetLastError());
+    }
     return GT_OK;
 }
 
@@ -271,7 +419,17 @@ int gt_dist_free(gt_dist *d) {
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     if (d->d_word) (void)hipFree(d->d_word);
     if (d->tmp) (void)hipFree(d->tmp);
+    for (void *q : {(void *)d->d_stab, (void *)d->d_cnt, (void *)d->d_cur, (void *)d->d_smode, (void *)d->d_cx, (void *)d->pairs_send, (void *)d->pairs_recv}) if (q) (void)hipFree(q);
     delete d;
+    return GT_OK;
+}
+
+int gt_dist_exchange_stats(gt_dist *d, uint64_t *bytes_sent, uint64_t *bytes_dense, uint64_t *exchanges, int reset) {
+    GT_REQUIRE(d, GT_ERR_INVALID, "null argument");
+    if (bytes_sent) *bytes_sent = d->bytes_sent;
+    if (bytes_dense) *bytes_dense = d->bytes_dense;
+    if (exchanges) *exchanges = d->exchanges;
+    if (reset) d->bytes_sent = d->bytes_dense = d->exchanges = 0;
     return GT_OK;
 }
 
@@ -293,6 +451,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     const bool col = (p->prm.order == GT_COL);
     const uint32_t K = g->info.x_slices;
     hipStream_t s = p->stream;
+    d->sp_graph = nullptr;   // block tables of the sparse exchange: rebuilt per call (a freed graph's address may come back)
     if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
     (void)gt_program_enable_timing(p, stats != nullptr);
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
@@ -304,7 +463,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
         if (!col && !p->converged) {
             st = exchange_issue(d, p, s); if (st != GT_OK) return st;
             for (uint32_t k = 0; k < K; k++) {
-                st = exchange_consume(d, k, s); if (st != GT_OK) return st;
+                st = exchange_consume(d, p, k, s); if (st != GT_OK) return st;
                 st = (K > 1) ? gt_program_combine_slice(p, k) : gt_program_combine(p); if (st != GT_OK) return st;
             }
         } else {

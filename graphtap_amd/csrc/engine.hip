@@ -123,10 +123,14 @@ template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
                                TX *__restrict__ x, double alpha, double tol, int cf, int last,
-                               unsigned long long *d_active, const uint8_t *__restrict__ bin_done) {
+                               unsigned long long *d_active, const uint32_t *__restrict__ bins, uint32_t nbins_listed) {
+    // bins == null: every row. Otherwise only the rows of the listed row bins (the ones phase 2 did not apply itself, pb.hip).
+    constexpr uint32_t RB = GT_PB_ROW_BIN_BITS, RR = 1u << RB;
+    const uint64_t n = bins ? (uint64_t)nbins_listed << RB : nr;
     unsigned act = 0;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
-        if (bin_done && bin_done[r >> GT_PB_ROW_BIN_BITS]) continue;   // applied by the fused flush of phase 2 (pb.hip)
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = bins ? bins[t >> RB] * RR + (uint32_t)(t & (RR - 1)) : (uint32_t)t;
+        if (r >= nr) continue;
         const uint32_t c = R2C[r];
         const bool source = (c == 0xFFFFFFFFu);
         const double yr = y[r];
@@ -762,12 +766,15 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         case GT_PR: {
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
             void *xm = p->xseg ? p->xseg : p->x;   // next iteration's messages of the owned columns
-            if (nr && p->x_f32)
-                k_pr_apply_msg<float><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
-                                                                   p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
-            else if (nr)
-                k_pr_apply_msg<double><<<grid_for(nr), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
-                                                                    p->prm.alpha, p->prm.tol, cf, last, d_active, fused ? gt_pb_bin_single(g) : nullptr);
+            uint32_t nlist = 0;
+            const uint32_t *list = fused ? gt_pb_split_bins(g, &nlist) : nullptr;   // after a fused combine: only the bins phase 2 left
+            const uint64_t nwork = list ? (uint64_t)nlist << GT_PB_ROW_BIN_BITS : nr;
+            if (nwork && p->x_f32)
+                k_pr_apply_msg<float><<<grid_for(nwork), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
+                                                                      p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist);
+            else if (nwork)
+                k_pr_apply_msg<double><<<grid_for(nwork), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
+                                                                       p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
         }

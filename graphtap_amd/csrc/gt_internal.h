@@ -165,6 +165,7 @@ struct gt_pr_epilogue {
     unsigned long long *d_active;
 };
 const uint8_t *gt_pb_bin_single(const gt_graph *g);   // [row bins] 1 = one phase-2 workgroup owns the bin
+const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n);   // the bins that are NOT single (device list): the only rows the apply kernel visits after a fused combine
 uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,

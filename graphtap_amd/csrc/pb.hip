@@ -776,6 +776,8 @@ struct gt_pb {
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice (and kind), largest chunk first
     uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
+    uint32_t *split_bins = nullptr;     // [nsplit] the other bins (with entries): their rows go through y and the apply kernel
+    uint32_t nsplit = 0;
     uint32_t rows_single = 0;           // rows of those bins
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
@@ -785,7 +787,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single, pb->split_bins};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete pb;
 }
@@ -1113,6 +1115,11 @@ int gt_pb_build(gt_graph *g) {
         for (BinWork &w : work) w.single = single[w.bin];
         PB_MALLOC(pb->bin_single, pb->nbins);
         PB_HIP(hipMemcpy(pb->bin_single, single.data(), pb->nbins, hipMemcpyHostToDevice));
+        std::vector<uint32_t> split;
+        for (uint32_t b = 0; b < pb->nbins; b++) if (!single[b]) split.push_back(b);   // incl. bins without entries: nobody else applies their rows
+        pb->nsplit = (uint32_t)split.size();
+        PB_MALLOC(pb->split_bins, (uint64_t)std::max<size_t>(split.size(), 1) * 4);
+        if (!split.empty()) PB_HIP(hipMemcpy(pb->split_bins, split.data(), split.size() * 4, hipMemcpyHostToDevice));
         if (stats) fprintf(stderr, "[pb] phase 2: %u workgroups for %u bins, %u of %u rows in single-workgroup bins\n", pb->nwork, pb->nbins, pb->rows_single, nr);
     }
     // largest first: the workgroups of a launch are dispatched in order and one fits per CU (128 KiB of LDS), so the
@@ -1197,6 +1204,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
 }
 
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
+const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n) { *n = g->pb ? g->pb->nsplit : 0; return g->pb ? g->pb->split_bins : nullptr; }
 uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
 uint64_t gt_pb_source_entries(const gt_graph *g) { return g->pb ? g->pb->nnz_source : 0; }
 

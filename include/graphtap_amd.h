@@ -292,6 +292,11 @@ int gt_dist_free(gt_dist *d);
 /* execute(n), vp:408-441, over all ranks: every rank calls it with its own program (same kind, graphs built from the
  * same edge list with rank / nranks of this communicator). iters == 0 runs until converged. */
 int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats);
+/* Bytes this rank's exchanges of x moved since the last reset (to other ranks and to itself), what the same exchanges
+ * would have moved as dense blocks, and their number. The min programs ship a (slice, peer) block whose active
+ * messages (!= infinity()) are fewer than half of its elements as (index, value) pairs -- the reference's sparse broadcast,
+ * vp:970-1013 with the count header of vp:766-773 -- after a count exchange; GRAPHTAP_SPARSE_EXCHANGE=0 keeps every block dense. */
+int gt_dist_exchange_stats(gt_dist *d, uint64_t *bytes_sent, uint64_t *bytes_dense, uint64_t *exchanges, int reset);
 /* sum over ranks of `count` (<= 64) host words, in place: checksum() (vp:1940, 1956), nnz_global, display() */
 int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count);
 

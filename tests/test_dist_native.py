@@ -100,9 +100,29 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
             G = gt.Graph(); G.load_edges(c["edges"], nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
         ps = [gt.BFS_Program(G, False, False, True, gt._ROW_) for G in Gs]
         for p in ps: p.root = c["root"]; p.initialize()
+        for d in dists: gt._lib.check(L.gt_dist_exchange_stats(d, None, None, None, 1))
         it, conv = _dist_execute_all(gt, dists, ps, 0)
         assert conv
         assert (_gather(ps, "parent", n) == c["np1_bfs_a"]).all() and (_gather(ps, "hops", n) == c["np1_bfs_b"]).all()
+        # sparse frontier exchange (vp:970-1013): a BFS frontier is a few vertices for most of its iterations, so the ranks
+        # must have shipped fewer bytes than the dense blocks hold -- unless it is switched off
+        sent, dense, nx = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        tot_sent = tot_dense = 0
+        for d in dists:
+            gt._lib.check(L.gt_dist_exchange_stats(d, C.byref(sent), C.byref(dense), C.byref(nx), 1))
+            tot_sent += sent.value; tot_dense += dense.value
+            assert nx.value == it
+        assert tot_sent < tot_dense, (tot_sent, tot_dense)
+        monkeypatch.setenv("GRAPHTAP_SPARSE_EXCHANGE", "0")
+        for p in ps: p.initialize()
+        it2, _ = _dist_execute_all(gt, dists, ps, 0)
+        assert it2 == it and (_gather(ps, "parent", n) == c["np1_bfs_a"]).all()
+        tot_sent = tot_dense = 0
+        for d in dists:
+            gt._lib.check(L.gt_dist_exchange_stats(d, C.byref(sent), C.byref(dense), C.byref(nx), 1))
+            tot_sent += sent.value; tot_dense += dense.value
+        assert tot_sent == tot_dense
+        monkeypatch.delenv("GRAPHTAP_SPARSE_EXCHANGE")
         for p in ps: p.free()
         for G in Gs: G.free()
         # CC (self loops kept)
