@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgraphtap_amd.so")
-SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip", "dist.hip"]
+SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip", "dist.hip", "tcsc_cf.hip"]
 
 
 def _stale():

@@ -36,6 +36,11 @@ class TileArrays(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("JA", "IA", "A", "JC", "IR", "L2G")]
 
 
+class TileCFArrays(C.Structure):
+    _fields_ = [("IA", C.c_void_p), ("A", C.c_void_p), ("JA_REG_R_NNZ_C", C.c_void_p), ("NC", C.c_uint32 * 4),
+                ("JA", C.c_void_p * 4), ("JC", C.c_void_p * 4)]
+
+
 class ExchangePlan(C.Structure):
     _fields_ = [("nranks", C.c_uint32), ("x_slices", C.c_uint32),
                 ("send_offset", C.POINTER(C.c_uint64)), ("recv_offset", C.POINTER(C.c_uint64)),
@@ -101,6 +106,8 @@ SIGNATURES = {
     "gt_dist_all_reduce_u64": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_uint32]),
     "gt_dist_exchange_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "gt_spmv": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "gt_spmv_cf": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "gt_graph_tile_cf": (C.c_int, [_vp, C.POINTER(TileCFArrays)]),
     "gt_rmat_generate": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, _vp]),
     "gt_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "gt_free": (C.c_int, [_vp]),

@@ -272,6 +272,7 @@ int gt_graph_free(gt_graph *g) {
     void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx, g->xslot, g->xcol, g->XV, g->R2X, g->x_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     gt_pb_free(g->pb);
+    gt_tcsc_cf_free(g->cf);
     delete g;
     return GT_OK;
 }
@@ -368,6 +369,10 @@ int gt_graph_tile(const gt_graph *g, gt_tile_arrays *a) {
     a->JA = g->JA; a->IA = g->IA; a->A = g->A; a->JC = g->JC; a->IR = g->IR; a->L2G = g->loc2glob;
     return GT_OK;
 }
+int gt_graph_tile_cf(gt_graph *g, gt_tile_cf_arrays *a) {
+    GT_REQUIRE(g && a, GT_ERR_INVALID, "null argument");
+    return gt_tcsc_cf_arrays(g, a);
+}
 int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan) {
     GT_REQUIRE(g && plan, GT_ERR_INVALID, "null argument");
     plan->nranks = g->info.nranks; plan->x_slices = g->info.x_slices;
@@ -376,19 +381,32 @@ int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan) {
     return GT_OK;
 }
 
+// the caller's x (compressed-column order) in the slot order the kernels read, or x itself under the identity layout
+static int x_in_slot_order(const gt_graph *g, const void **x_dev, uint32_t w, hipStream_t s) {
+    if (!(g->xslot && g->info.nnzcols)) return GT_OK;
+    gt_graph *gm = const_cast<gt_graph *>(g);
+    if (!gm->x_scratch) GT_HIP(hipMalloc(&gm->x_scratch, (uint64_t)g->x_len * 8));
+    GT_HIP(hipMemsetAsync(gm->x_scratch, 0, (uint64_t)g->x_len * w, s));   // unused slots are never referenced by an entry
+    if (w == 8) k_to_slots<uint64_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint64_t *)*x_dev, g->xslot, g->info.nnzcols, (uint64_t *)gm->x_scratch);
+    else k_to_slots<uint32_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)*x_dev, g->xslot, g->info.nnzcols, (uint32_t *)gm->x_scratch);
+    GT_HIP(hipGetLastError());
+    *x_dev = gm->x_scratch;
+    return GT_OK;
+}
+
+int gt_spmv_cf(gt_graph *g, const void *x_dev, void *y_dev, int first_iteration, int running, int last_iteration, void *hip_stream) {
+    GT_REQUIRE(g && x_dev && y_dev, GT_ERR_INVALID, "null argument");
+    int st = gt_tcsc_cf_build(g);   // before x is staged: a failed build leaves nothing behind
+    if (st != GT_OK) return st;
+    st = x_in_slot_order(g, &x_dev, 8, (hipStream_t)hip_stream);
+    if (st != GT_OK) return st;
+    return gt_tcsc_cf_spmv(g, (const double *)x_dev, (double *)y_dev, first_iteration != 0, running != 0, last_iteration != 0, (hipStream_t)hip_stream);
+}
+
 int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream) {
     GT_REQUIRE(g && x_dev && y_dev, GT_ERR_INVALID, "null argument");
-    if (g->xslot && g->info.nnzcols) {   // hubs-first layout: the kernels read x by slot; the ABI's x is in compressed-column order
-        const uint32_t w = (semiring == GT_PLUS_F64) ? 8 : 4;
-        gt_graph *gm = const_cast<gt_graph *>(g);
-        if (!gm->x_scratch) GT_HIP(hipMalloc(&gm->x_scratch, (uint64_t)g->x_len * 8));
-        hipStream_t s = (hipStream_t)hip_stream;
-        GT_HIP(hipMemsetAsync(gm->x_scratch, 0, (uint64_t)g->x_len * w, s));   // unused slots are never referenced by an entry
-        if (w == 8) k_to_slots<uint64_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint64_t *)x_dev, g->xslot, g->info.nnzcols, (uint64_t *)gm->x_scratch);
-        else k_to_slots<uint32_t><<<grid_for(g->info.nnzcols), TPB, 0, s>>>((const uint32_t *)x_dev, g->xslot, g->info.nnzcols, (uint32_t *)gm->x_scratch);
-        GT_HIP(hipGetLastError());
-        x_dev = gm->x_scratch;
-    }
+    int st = x_in_slot_order(g, &x_dev, (semiring == GT_PLUS_F64) ? 8 : 4, (hipStream_t)hip_stream);   // hubs-first layout: the kernels read x by slot
+    if (st != GT_OK) return st;
     return gt_launch_spmv(g, semiring, x_dev, y_dev, (hipStream_t)hip_stream);
 }
 
@@ -655,7 +673,17 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         const bool skip_source = p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF && p->cf_hint && !cf_last && gt_pb_source_entries(g) != 0 &&
                                  !getenv("GRAPHTAP_NO_CF_FILTER");
         if (skip_source) p->cf_filtered++;
-        int st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source);
+        // the edge-parallel baseline runs a GT_TCSC_CF PageRank over the format's own pair lists (vp:1243-1317)
+        const bool cf_lists = g->spmv_variant == GT_SPMV_EDGE && p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF && !gt_has_exchange(g) &&
+                              !getenv("GRAPHTAP_NO_CF_FILTER");
+        int st;
+        if (cf_lists) {
+            const bool last = !p->cf_hint || cf_last;   // stepped without a hint: source rows every time (only the last apply reads them)
+            if (!last) p->cf_filtered++;
+            st = gt_tcsc_cf_spmv(const_cast<gt_graph *>(g), (const double *)p->x, (double *)p->y, p->iteration == 0, true, last, s);
+        } else {
+            st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source);
+        }
         if (st != GT_OK) return st;
         p->fused = fuse;
         if (timed) { GT_HIP(hipEventRecord(e1, s)); if (hi >= K) p->spmv_done++; }

@@ -70,6 +70,7 @@ struct gt_graph {
     void *x_scratch = nullptr;     // [x_len] x 8 B: gt_spmv's copy of a caller's compressed-order x in slot order
     bool force_exchange = false;  // GRAPHTAP_FORCE_EXCHANGE: exchange layout on a single rank (rehearses the N-rank driver path)
     struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
+    struct gt_tcsc_cf *cf = nullptr;  // the tile in TCSC_CF form, built on first use (tcsc_cf.hip)
     int spmv_variant = 1;        // gt_spmv_variant
 };
 
@@ -173,6 +174,13 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
 uint64_t gt_pb_source_entries(const gt_graph *g);   // entries in chunks of source rows (left out by PageRank/TCSC_CF until the last iteration)
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
+
+// tcsc_cf.hip
+int gt_tcsc_cf_build(gt_graph *g);
+void gt_tcsc_cf_free(struct gt_tcsc_cf *c);
+int gt_tcsc_cf_arrays(gt_graph *g, gt_tile_cf_arrays *a);
+// the pair-list SpMV of vp:1243-1317; x in slot order (g->xslot), accumulates into y
+int gt_tcsc_cf_spmv(gt_graph *g, const double *x, double *y, bool first, bool running, bool last, hipStream_t s);
 
 // Original vertex id of state slot / internal id u. One rank (identity map): u itself, also for the padding slot
 // u = nrows, exactly like the reference's get_vid (vp:1805-1808). Several ranks: ~0u when u is not a vertex.

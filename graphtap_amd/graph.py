@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import ExchangePlan, GraphFlags, GraphInfo, GraphTapError, TileArrays, check, lib
+from ._lib import ExchangePlan, GraphFlags, GraphInfo, GraphTapError, TileArrays, TileCFArrays, check, lib
 
 # Tiling_type (src/mat/tiling.hpp:13-16) / Compression_type (src/ds/compressed_column.hpp)
 _2D_, _2DT_ = 0, 1
@@ -153,6 +153,29 @@ class Graph:
         return dict(JA=grab(t.JA, ncols_total + 1), IA=grab(t.IA, i.nnz_local),
                     A=grab(t.A, i.nnz_local) if t.A else None, JC=grab(t.JC, i.nnzcols), IR=grab(t.IR, i.nnzrows),
                     L2G=grab(t.L2G, ncols_total) if t.L2G else None)
+
+    CF_LISTS = ("REG_R_REG_C", "REG_R_SNK_C", "SRC_R_REG_C", "SRC_R_SNK_C")   # gt_cf_list
+
+    def tile_cf(self):
+        """gt_graph_tile_cf: the tile in TCSC_CF form (device pointers; built on first use)."""
+        t = TileCFArrays()
+        check(lib().gt_graph_tile_cf(self._h, C.byref(t)))
+        return t
+
+    def tile_cf_to_host(self):
+        """The TCSC_CF arrays as numpy, named like TCSC_CF_BASE's members (ds/compressed_column.hpp:419-470)."""
+        t, i = self.tile_cf(), self.info
+
+        def grab(ptr, n):
+            a = np.zeros(n, np.uint32)
+            if n and ptr:
+                check(lib().gt_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, n * 4))
+            return a
+        out = dict(IA=grab(t.IA, i.nnz_local), A=grab(t.A, i.nnz_local) if t.A else None, JA_REG_R_NNZ_C=grab(t.JA_REG_R_NNZ_C, 2 * i.nnzcols))
+        for k, name in enumerate(self.CF_LISTS):
+            out["NC_" + name] = int(t.NC[k])
+            out["JA_" + name] = grab(t.JA[k], 2 * int(t.NC[k])); out["JC_" + name] = grab(t.JC[k], int(t.NC[k]))
+        return out
 
     def exchange_plan(self):
         """gt_graph_exchange_plan as python lists: (send_offset[K+1], recv_offset[K+1], send_counts[K][p], recv_counts[K][p])."""

@@ -107,6 +107,27 @@ typedef struct gt_tile_arrays {
                            column j), UINT32_MAX for padding; NULL on one rank   */
 } gt_tile_arrays;
 
+/* The same tile in TCSC_CF form (TCSC_CF_BASE, ds/compressed_column.hpp:419-470), device pointers; one rank only. JA, JC
+ * and IR are those of gt_tile_arrays. Inside every column of IA (and A) the entries of SOURCE rows -- rows whose vertex has
+ * no column -- sit in the column's tail, in exactly the order the reference's swaps leave them and the regular rows in
+ * (:671-708). The four pair lists (:744-1113) are indexed by gt_cf_list: pair q of list k is the range
+ * [JA[k][2q], JA[k][2q+1]) of IA, JC[k][q] its compressed column. GT_CF_SRC_R_SNK_C is NC entries long but only its leading
+ * pairs are filled, the rest are zero (empty ranges), as in the reference (:1040-1062). */
+typedef enum gt_cf_list {
+    GT_CF_REG_R_REG_C = 0, /* regular rows of regular columns: every iteration           (vp:1264-1281) */
+    GT_CF_REG_R_SNK_C = 1, /* regular rows of sink columns:    iteration 0 only          (vp:1246-1262) */
+    GT_CF_SRC_R_REG_C = 2, /* source rows of regular columns:  the last iteration only   (vp:1282-1297) */
+    GT_CF_SRC_R_SNK_C = 3  /* source rows of sink columns:     the last iteration only   (vp:1298-1313) */
+} gt_cf_list;
+typedef struct gt_tile_cf_arrays {
+    const uint32_t *IA;             /* [nnz_local]                                         */
+    const uint32_t *A;              /* [nnz_local] weights moved with their entries, or NULL */
+    const uint32_t *JA_REG_R_NNZ_C; /* [2 * nnzcols] regular rows of every column (:713-742) */
+    uint32_t NC[4];
+    const uint32_t *JA[4];          /* [2 * NC[k]] */
+    const uint32_t *JC[4];          /* [NC[k]]     */
+} gt_tile_cf_arrays;
+
 /* The exchange of the message vector between ranks, replacing the reference's MPI_Ibcast of every x segment down its
  * column group (vp:843-862, 970-1013). A tile-row only reads the columns it has an entry in (47 % of all non-empty
  * columns at 8 ranks on R-MAT-26), so instead of all-gathering whole segments every rank SENDS to rank d just the
@@ -193,6 +214,8 @@ int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
  * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
 int gt_graph_select_spmv(gt_graph *g, int variant);
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
+/* Builds the TCSC_CF form on first use (Matrix::init_tcsc_cf, mat/matrix.hpp:1370-1403); the arrays live until gt_graph_free. */
+int gt_graph_tile_cf(gt_graph *g, gt_tile_cf_arrays *arrays);
 int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan);
 /* Original vertex id of the first `count` (<= tile_height) state slots of this handle, UINT32_MAX for a padding
  * slot. On one rank slot i is vertex i (the reference's layout, vp:1805-1808). On several ranks the owned
@@ -306,6 +329,12 @@ int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count);
  * y is accumulated into (the caller zero/INF-fills it). Columns whose message is
  * GT_INF are skipped under the two min semirings (vp:1492). */
 int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, void *hip_stream);
+/* spmv_stationary over the TCSC_CF pair lists in _ROW_ order (vp:1243-1317), plus-times over f64: regular rows of sink
+ * columns when `first_iteration`, regular rows of regular columns when `running` (the program has not converged), source
+ * rows when `last_iteration`. x: nnzcols doubles in compressed-column order, y: nnzrows doubles, accumulated into. This is
+ * what a PageRank created with GT_TCSC_CF runs on the GT_SPMV_EDGE variant; the propagation-blocking variants apply the
+ * same filter to their own streams (gt_exec_stats.cf_filtered_iterations). */
+int gt_spmv_cf(gt_graph *g, const void *x_dev, void *y_dev, int first_iteration, int running, int last_iteration, void *hip_stream);
 
 /* ---- synthetic input (no generator in the reference) --------
  * Writes records [first, first+count) of the counter-based R-MAT stream

@@ -194,6 +194,133 @@ void gto_class_counts(const gto_graph *g, uint32_t *regular, uint32_t *source_ro
     *regular = r; *source_rows = s; *sink_cols = t;
 }
 
+/* ------------------------------------------------------------- TCSC_CF */
+/*
+ * The tile in TCSC_CF_BASE form (ds/compressed_column.hpp:419-470), built
+ * from the TCSC arrays the way populate() does it after its TCSC part
+ * (:671-1120). A row is a SOURCE row when its vertex has no column
+ * (source_rows_bitvector, mat/matrix.hpp:1125-1144); a column is REGULAR
+ * when its vertex has a row too, a SINK column otherwise.
+ *   IA (and A) : per column the source-row entries are swapped to the tail;
+ *                the swap order is the reference's (:671-708), so the
+ *                regular entries end up in the reference's order as well.
+ *   lists 0..3 : REG_R_REG_C, REG_R_SNK_C, SRC_R_REG_C, SRC_R_SNK_C -- pairs
+ *                [begin, end) into IA plus the compressed column of each.
+ * Pinned against arrays dumped from the unmodified reference
+ * (tests/golden/tcsc_cf.npz, tests/golden/make_tcsc_cf_golden.py).
+ */
+typedef struct gto_tcsc_cf {
+    uint64_t nnz; uint32_t nnzcols;
+    uint32_t *IA, *A;
+    uint32_t *JA_REG_R_NNZ_C;           /* [2 * nnzcols], :713-742 */
+    uint32_t NC[4]; uint32_t *JA[4], *JC[4];
+} gto_tcsc_cf;
+
+void gto_tcsc_cf_free(gto_tcsc_cf *c) {
+    if (!c) return;
+    free(c->IA); free(c->A); free(c->JA_REG_R_NNZ_C);
+    for (int k = 0; k < 4; k++) { free(c->JA[k]); free(c->JC[k]); }
+    free(c);
+}
+
+gto_tcsc_cf *gto_tcsc_cf_build(const gto_graph *g) {
+    const uint32_t nc = g->nnzcols;
+    const uint32_t *JA = g->JA;
+    gto_tcsc_cf *c = (gto_tcsc_cf *)calloc(1, sizeof(gto_tcsc_cf));
+    c->nnz = g->nnz; c->nnzcols = nc;
+    c->IA = (uint32_t *)malloc((g->nnz ? g->nnz : 1) * sizeof(uint32_t));
+    memcpy(c->IA, g->IA, g->nnz * sizeof(uint32_t));
+    if (g->A) { c->A = (uint32_t *)malloc((g->nnz ? g->nnz : 1) * sizeof(uint32_t)); memcpy(c->A, g->A, g->nnz * sizeof(uint32_t)); }
+    uint32_t *IA = c->IA, *A = c->A;
+#define IS_SRC(i) (!g->J[g->IR[IA[i]]])
+    uint32_t *nsrc = (uint32_t *)calloc((size_t)nc + 1, sizeof(uint32_t));
+    uint32_t *r = (uint32_t *)malloc((g->nnz ? g->nnz : 1) * sizeof(uint32_t));
+    /* :671-708 -- for every source entry of a column, front to back: walk from the column's end towards the front;
+       the first entry of a regular row found is swapped with it; reaching the entry itself first ends the walk */
+    for (uint32_t j = 0; j < nc; j++) {
+        uint32_t n = 0, m = JA[j + 1] - JA[j];
+        for (uint32_t i = JA[j]; i < JA[j + 1]; i++) if (IS_SRC(i)) r[n++] = i;
+        nsrc[j] = n;
+        if (n == 0 || m == n) continue;
+        for (uint32_t p = 0; p < n; p++) {
+            for (uint32_t q = JA[j + 1]; q-- > JA[j];) {
+                if (!IS_SRC(q)) {
+                    uint32_t t = IA[r[p]]; IA[r[p]] = IA[q]; IA[q] = t;
+                    if (A) { t = A[r[p]]; A[r[p]] = A[q]; A[q] = t; }
+                    break;
+                }
+                if (r[p] == q) break;
+            }
+        }
+    }
+#undef IS_SRC
+    free(r);
+    /* :713-742 regular rows of every non-empty column */
+    c->JA_REG_R_NNZ_C = (uint32_t *)calloc(2 * (size_t)nc + 1, sizeof(uint32_t));
+    for (uint32_t j = 0; j < nc; j++) { c->JA_REG_R_NNZ_C[2 * j] = JA[j]; c->JA_REG_R_NNZ_C[2 * j + 1] = JA[j + 1] - nsrc[j]; }
+    /* the four lists walk the columns that have entries in this tile and are regular / sink (:744-1113) */
+    for (int k = 0; k < 4; k++) {
+        const int want_regular_col = (k == 0 || k == 2);
+        /* sizes: lists 0 and 1 count the columns with at least one regular row (:744-775, :846-875); list 2 the columns
+           with at least one source row (:952-975); list 3 counts SOURCE ENTRIES, not columns (:1040-1060: k++ per entry),
+           so it is longer than what gets filled -- the rest stays zero */
+        uint32_t count = 0;
+        for (uint32_t j = 0; j < nc; j++) {
+            if (JA[j] == JA[j + 1] || (g->I[g->JC[j]] != 0) != want_regular_col) continue;
+            uint32_t m = JA[j + 1] - JA[j], n = nsrc[j];
+            if (k < 2) count += (m != n);
+            else if (k == 2) count += (n > 0);
+            else count += n;
+        }
+        c->NC[k] = count;
+        c->JA[k] = (uint32_t *)calloc(2 * (size_t)count + 1, sizeof(uint32_t));
+        c->JC[k] = (uint32_t *)calloc((size_t)count + 1, sizeof(uint32_t));
+        if (!count) continue;
+        uint32_t o = 0;
+        for (uint32_t j = 0; j < nc; j++) {
+            if (JA[j] == JA[j + 1] || (g->I[g->JC[j]] != 0) != want_regular_col) continue;
+            uint32_t m = JA[j + 1] - JA[j], n = nsrc[j];
+            if (k < 2) {                 /* :790-843, :888-940 */
+                if (m == n) continue;
+                c->JA[k][2 * o] = JA[j]; c->JA[k][2 * o + 1] = JA[j + 1] - n;
+            } else if (k == 2) {         /* :990-1035 */
+                if (!n) continue;
+                c->JA[k][2 * o] = JA[j + 1] - n; c->JA[k][2 * o + 1] = JA[j + 1];
+            } else {                     /* :1075-1113: the pair starts at JA[j] + n, as the reference writes it */
+                if (!n) continue;
+                c->JA[k][2 * o] = JA[j] + n; c->JA[k][2 * o + 1] = JA[j + 1];
+            }
+            c->JC[k][o++] = j;
+        }
+    }
+    free(nsrc);
+    return c;
+}
+
+const uint32_t *gto_cf_IA(const gto_tcsc_cf *c) { return c->IA; }
+const uint32_t *gto_cf_A(const gto_tcsc_cf *c) { return c->A; }
+const uint32_t *gto_cf_nnz_pairs(const gto_tcsc_cf *c) { return c->JA_REG_R_NNZ_C; }
+uint32_t gto_cf_count(const gto_tcsc_cf *c, int k) { return c->NC[k]; }
+const uint32_t *gto_cf_pairs(const gto_tcsc_cf *c, int k) { return c->JA[k]; }
+const uint32_t *gto_cf_cols(const gto_tcsc_cf *c, int k) { return c->JC[k]; }
+
+/* spmv_stationary on a TCSC_CF tile in _ROW_ order, vp/vertex_program.hpp:1243-1317: regular rows from sink columns on
+   iteration 0 only, regular rows from regular columns while the program runs, source rows on the last iteration. The
+   caller passes the three conditions; the SRC_R_SNK_C list is walked over all NC pairs, zero-filled ones included
+   (they are empty ranges), and only when NC_SRC_R_REG_C != 0 (:1298), as in the reference. */
+void gto_spmv_cf_plus_f64(const gto_tcsc_cf *c, const double *x, double *y, int first, int running, int last) {
+    const int use[4] = {running, first, last, last && c->NC[2] != 0};
+    const int order[4] = {1, 0, 2, 3};
+    for (int o = 0; o < 4; o++) {
+        const int k = order[o];
+        if (!use[k]) continue;
+        for (uint32_t j = 0; j < c->NC[k]; j++) {
+            const double xl = x[c->JC[k][j]];
+            for (uint32_t i = c->JA[k][2 * j]; i < c->JA[k][2 * j + 1]; i++) y[c->IA[i]] += xl;
+        }
+    }
+}
+
 /* ------------------------------------------------------ kernel-level SpMV */
 /* K1, vp/vertex_program.hpp:1162-1173: y[IA[i]] += x[j]   (plus-times, unweighted) */
 void gto_spmv_plus_f64(const gto_graph *g, const double *x, double *y) {

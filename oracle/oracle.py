@@ -45,6 +45,18 @@ def _load():
     lib.gto_spmv_plus_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gto_spmv_min_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gto_degree.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.gto_tcsc_cf_build.restype = C.c_void_p
+    lib.gto_tcsc_cf_build.argtypes = [C.c_void_p]
+    lib.gto_tcsc_cf_free.argtypes = [C.c_void_p]
+    for name in ("gto_cf_IA", "gto_cf_A", "gto_cf_nnz_pairs"):
+        getattr(lib, name).restype = _u32p
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.gto_cf_count.restype = C.c_uint32
+    lib.gto_cf_count.argtypes = [C.c_void_p, C.c_int]
+    for name in ("gto_cf_pairs", "gto_cf_cols"):
+        getattr(lib, name).restype = _u32p
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
+    lib.gto_spmv_cf_plus_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.gto_pagerank.restype = C.c_uint32
     lib.gto_pagerank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_double, C.c_double,
                                  C.c_void_p, C.c_void_p]
@@ -118,6 +130,34 @@ class OracleGraph:
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib().gto_class_counts(self._h, C.byref(a), C.byref(b), C.byref(c))
         return {"regular": a.value, "source_rows": b.value, "sink_cols": c.value}
+
+    CF_LISTS = ("REG_R_REG_C", "REG_R_SNK_C", "SRC_R_REG_C", "SRC_R_SNK_C")
+
+    def tcsc_cf(self):
+        """The tile in TCSC_CF_BASE form (ds/compressed_column.hpp:419-470, 671-1120): dict of arrays named like the
+        reference's members (IA, A, JA_REG_R_NNZ_C, NC_*/JA_*/JC_* of the four lists)."""
+        L = lib()
+        h = L.gto_tcsc_cf_build(self._h)
+        def arr(p, n):
+            return np.ctypeslib.as_array(p, shape=(n,)).copy() if n and p else np.zeros(0, np.uint32)
+        out = {"IA": arr(L.gto_cf_IA(h), self.nnz), "A": arr(L.gto_cf_A(h), self.nnz) if self.weighted else None,
+               "JA_REG_R_NNZ_C": arr(L.gto_cf_nnz_pairs(h), 2 * self.nnzcols)}
+        for k, name in enumerate(self.CF_LISTS):
+            n = L.gto_cf_count(h, k)
+            out["NC_" + name] = n
+            out["JA_" + name] = arr(L.gto_cf_pairs(h, k), 2 * n); out["JC_" + name] = arr(L.gto_cf_cols(h, k), n)
+        L.gto_tcsc_cf_free(h)
+        return out
+
+    def spmv_cf_plus_f64(self, x, y, *, first, running, last):
+        """spmv_stationary over the TCSC_CF pair lists (vp:1243-1317); y is accumulated into."""
+        x = np.ascontiguousarray(x, np.float64); assert x.shape == (self.nnzcols,)
+        assert y.dtype == np.float64 and y.shape == (self.nnzrows,) and y.flags.c_contiguous
+        L = lib()
+        h = L.gto_tcsc_cf_build(self._h)
+        L.gto_spmv_cf_plus_f64(h, _ptr(x), _ptr(y), int(first), int(running), int(last))
+        L.gto_tcsc_cf_free(h)
+        return y
 
     def spmv_plus_f64(self, x, y):
         x = np.ascontiguousarray(x, np.float64); assert x.shape == (self.nnzcols,)

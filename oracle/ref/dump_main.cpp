@@ -10,7 +10,20 @@
  * the reference itself and not from a re-implementation.
  *
  * Select the program at compile time: -DAPP_DEG | -DAPP_PR | -DAPP_PR1 |
- * -DAPP_BFS | -DAPP_SSSP (+ -DHAS_WEIGHT) | -DAPP_CC.
+ * -DAPP_BFS | -DAPP_SSSP (+ -DHAS_WEIGHT) | -DAPP_CC | -DAPP_TCSC_CF
+ * (+ -DHAS_WEIGHT).
+ *
+ * -DAPP_TCSC_CF (np = 1 only) runs no program: it loads the graph with the
+ * flags of src/apps/pr.cpp and writes the tile's TCSC_CF_BASE arrays
+ * (src/ds/compressed_column.hpp:419-470, all public members of the
+ * compressor) to `<out>.cf.bin`:
+ *   u32 magic 'GTCF', u32 weighted, u64 nnz, u32 nnzcols, u32 nnzrows,
+ *   IA[nnz], (A[nnz],) JA[nnzcols+1], JC[nnzcols], IR[nnzrows],
+ *   JA_REG_R_NNZ_C[2*nnzcols], then for REG_R_REG_C, REG_R_SNK_C,
+ *   SRC_R_REG_C, SRC_R_SNK_C: u32 NC, JA_*[2*NC], JC_*[NC].
+ * Graph::A and Matrix::tiles are private; they are read through the
+ * explicit-instantiation rule ([temp.explicit]: access checks do not apply
+ * to names in an explicit instantiation) -- the reference is not modified.
  *
  * File layout (little endian):
  *   u32 magic 'GTV1', u32 app, u32 rank, u32 nranks, u32 owned_segment,
@@ -45,6 +58,19 @@
 #elif defined(APP_CC)
 #include "cc.h"
 #define APP_ID 4
+#elif defined(APP_TCSC_CF)
+#ifdef HAS_WEIGHT
+#include "sssp.h"
+#else
+#include "pr.h"
+#endif
+#define APP_ID 5
+template <class Tag, typename Tag::type M>
+struct Expose { friend typename Tag::type peek(Tag) { return M; } };
+struct GraphA { typedef Matrix<wp, ip, fp>* Graph<wp, ip, fp>::*type; friend type peek(GraphA); };
+template struct Expose<GraphA, &Graph<wp, ip, fp>::A>;
+struct MatrixTiles { typedef std::vector<std::vector<struct Tile2D<wp, ip, fp>>> Matrix<wp, ip, fp>::*type; friend type peek(MatrixTiles); };
+template struct Expose<MatrixTiles, &Matrix<wp, ip, fp>::tiles>;
 #else
 #error "pick an APP_*"
 #endif
@@ -146,6 +172,40 @@ int main(int argc, char** argv) {
     V.checksum();
     dump(out, V, [](SSSP_State& s, Rec& r) { r.a = s.distance; });
     V.free();
+    G.free();
+#elif defined(APP_TCSC_CF)
+    if (Env::nranks != 1) { fprintf(stderr, "dump_tcsc_cf: np = 1 only\n"); Env::exit(1); }
+    Graph<wp, ip, fp> G;
+    G.load(file_path, num_vertices, num_vertices, true, true, true, false, true, TT, _TCSC_CF_);
+    {
+        Matrix<wp, ip, fp>* M = G.*peek(GraphA());
+        auto& tile = (M->*peek(MatrixTiles()))[0][0];
+        auto* c = static_cast<TCSC_CF_BASE<wp, ip>*>(tile.compressor);
+        char path[4096];
+        snprintf(path, sizeof(path), "%s.cf.bin", out);
+        FILE* f = fopen(path, "wb");
+        if (!f) { perror(path); Env::exit(1); }
+#ifdef HAS_WEIGHT
+        uint32_t weighted = 1;
+#else
+        uint32_t weighted = 0;
+#endif
+        uint32_t magic = 0x46435447u, nc = c->nnzcols, nr = c->nnzrows;
+        uint64_t nnz = c->nnz;
+        fwrite(&magic, 4, 1, f); fwrite(&weighted, 4, 1, f); fwrite(&nnz, 8, 1, f); fwrite(&nc, 4, 1, f); fwrite(&nr, 4, 1, f);
+        fwrite(c->IA, 4, nnz, f);
+#ifdef HAS_WEIGHT
+        fwrite(c->A, 4, nnz, f);
+#endif
+        fwrite(c->JA, 4, nc + 1, f); fwrite(c->JC, 4, nc, f); fwrite(c->IR, 4, nr, f);
+        fwrite(c->JA_REG_R_NNZ_C, 4, 2 * (size_t)nc, f);
+        auto list = [&](uint32_t n, ip* ja, ip* jc) { fwrite(&n, 4, 1, f); if (n) { fwrite(ja, 4, 2 * (size_t)n, f); fwrite(jc, 4, n, f); } };
+        list(c->NC_REG_R_REG_C, c->JA_REG_R_REG_C, c->JC_REG_R_REG_C);
+        list(c->NC_REG_R_SNK_C, c->JA_REG_R_SNK_C, c->JC_REG_R_SNK_C);
+        list(c->NC_SRC_R_REG_C, c->JA_SRC_R_REG_C, c->JC_SRC_R_REG_C);
+        list(c->NC_SRC_R_SNK_C, c->JA_SRC_R_SNK_C, c->JC_SRC_R_SNK_C);
+        fclose(f);
+    }
     G.free();
 #elif defined(APP_CC)
     Graph<wp, ip, fp> G;

@@ -30,6 +30,18 @@ def load_case(name):
     return z
 
 
+def load_cf_case(name):
+    """(edges, num_vertices, the reference's TCSC_CF arrays) of a case of tests/golden/tcsc_cf.npz (make_tcsc_cf_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "tcsc_cf.npz"))
+    if name == "mixed":
+        edges, nv = z["mixed_edges"], int(z["mixed_num_vertices"])
+    else:
+        c = load_case(name); edges, nv = c["edges"], c["num_vertices"]
+    pre = name + "_u_"
+    return edges, nv, {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+
+
+CF_CASES = ["tiny", "rmat8", "rmat10", "rmat12", "mixed"]
 CASES = ["tiny", "rmat8", "rmat10", "rmat12"]
 FIRST_NP = {"tiny": 1, "rmat8": 1, "rmat10": 1, "rmat12": 1}
 OTHER_NP = {"tiny": 2, "rmat8": 2, "rmat10": 4, "rmat12": 8}

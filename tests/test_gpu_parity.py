@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import CASES, load_case
+from conftest import CASES, CF_CASES, load_case, load_cf_case
 
 pytestmark = pytest.mark.gpu
 
@@ -167,6 +167,81 @@ def test_spmv_kernels_match_oracle(gt, O, name):
         assert (host(dy, y0) == want).all()
         L.gt_free(dx); L.gt_free(dy)
     G.free()
+
+
+@pytest.mark.parametrize("name", CF_CASES + ["rmat16", "weighted"])
+def test_tcsc_cf_format_matches_reference_and_oracle(gt, O, name):
+    """gt_graph_tile_cf: IA with the source rows of every column in its tail IN THE REFERENCE'S SWAP ORDER and the four
+    pair lists (ds/compressed_column.hpp:603-1120), bit for bit against the arrays dumped from the unmodified reference
+    (tests/golden/tcsc_cf.npz) and against the oracle's restatement on a larger R-MAT; with weights, A must travel with IA."""
+    weighted = name == "weighted"
+    if name == "rmat16":
+        from graphtap_amd.rmat import rmat_edges
+        edges, nv, ref = rmat_edges(16, 16, 4), 1 << 16, None
+    elif weighted:
+        edges, nv, ref = load_case("rmat12")["wedges"], 1 << 12, None
+    else:
+        edges, nv, ref = load_cf_case(name)
+    og = O.OracleGraph(edges, nv, weighted=weighted, **O.APP_FLAGS["pr"])
+    want = og.tcsc_cf()
+    G = gt.Graph(weighted=weighted); G.load_edges(edges, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    got = G.tile_cf_to_host()
+    keys = ["IA", "JA_REG_R_NNZ_C"] + [p + l for l in G.CF_LISTS for p in ("JA_", "JC_")]
+    for k in keys:
+        assert got[k].shape == want[k].shape and (got[k] == want[k]).all(), k
+        if ref is not None: assert (got[k] == ref[k]).all(), k
+    for l in G.CF_LISTS:
+        assert got["NC_" + l] == want["NC_" + l]
+    if weighted:
+        assert (got["A"] == want["A"]).all()
+        t = G.tile_to_host()
+        pairs = lambda ia, a: np.sort(ia.astype(np.uint64) << 32 | a)
+        for j in range(0, og.nnzcols, 7):
+            a, b = t["JA"][j], t["JA"][j + 1]
+            assert (pairs(got["IA"][a:b], got["A"][a:b]) == pairs(t["IA"][a:b], t["A"][a:b])).all()
+    assert (G.tile_cf_to_host()["IA"] == got["IA"]).all()   # second call: the same arrays, not a rebuild of something else
+    G.free()
+
+
+@pytest.mark.parametrize("variant", ["edge", "pb"])
+@pytest.mark.parametrize("name", CF_CASES)
+def test_tcsc_cf_pair_list_spmv_matches_oracle(gt, O, name, variant, monkeypatch):
+    """gt_spmv_cf = spmv_stationary's TCSC_CF branch (vp:1243-1317) for each of its three conditions; integer-valued
+    messages make the f64 sums exact in any order. Under both layouts of x (the pb build's hubs first, the edge build's)."""
+    monkeypatch.setenv("GRAPHTAP_SPMV", variant)
+    edges, nv, _ = load_cf_case(name)
+    L = gt._lib.lib()
+    og = O.OracleGraph(edges, nv, **O.APP_FLAGS["pr"])
+    G = gt.Graph(); G.load_edges(edges, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    rng = np.random.RandomState(3)
+    x = rng.randint(1, 1000, og.nnzcols).astype(np.float64)
+    dx, dy = C.c_void_p(), C.c_void_p()
+    gt._lib.check(L.gt_malloc(C.byref(dx), max(x.nbytes, 8))); gt._lib.check(L.gt_malloc(C.byref(dy), max(og.nnzrows * 8, 8)))
+    gt._lib.check(L.gt_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes))
+    for first, running, last in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 1, 1)):
+        y0 = rng.randint(0, 50, og.nnzrows).astype(np.float64)
+        want = og.spmv_cf_plus_f64(x, y0.copy(), first=first, running=running, last=last)
+        gt._lib.check(L.gt_memcpy_h2d(dy, y0.ctypes.data_as(C.c_void_p), y0.nbytes))
+        gt._lib.check(L.gt_spmv_cf(G._h, dx, dy, first, running, last, None))
+        got = np.zeros_like(y0); gt._lib.check(L.gt_memcpy_d2h(got.ctypes.data_as(C.c_void_p), dy, got.nbytes))
+        assert (got == want).all(), (first, running, last)
+    L.gt_free(dx); L.gt_free(dy); G.free()
+
+
+def test_tcsc_cf_pagerank_on_the_pair_lists(gt, known_answers, monkeypatch):
+    """A GT_TCSC_CF PageRank on the edge-parallel variant runs over the pair lists (regular rows every iteration, source
+    rows on the last one): the reference's ranks, fixed count and converge mode, and the statistics say so."""
+    monkeypatch.setenv("GRAPHTAP_SPMV", "edge")
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+        for iters, key in ((20, "np1_pr20"), (1, "np1_pr1"), (0, "np1_prconv_cf")):
+            r = run_pr(gt, c["edges"], nv, iters, cf=True)
+            ref = c[key + "_c"]
+            assert r["iterations"] == known_answers[name][key]["iterations"]
+            assert (np.abs(r["rank"][:n] - ref) / ref).max() < PR_RTOL and (r["degree"][:n] == c[key + "_a"]).all()
+            assert r["stats"].cf_filtered_iterations == (r["iterations"] if iters == 0 else iters - 1)
+        r = run_pr(gt, c["edges"], nv, 20, cf=False)
+        assert r["stats"].cf_filtered_iterations == 0 and (np.abs(r["rank"][:n] - c["np1_pr1app20_c"]) / c["np1_pr1app20_c"]).max() < PR_RTOL
 
 
 # ------------------------------------------------------------------------------- the five apps vs the reference

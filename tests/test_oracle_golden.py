@@ -12,7 +12,7 @@ sums across tiles there).
 import numpy as np
 import pytest
 
-from conftest import CASES, OTHER_NP, load_case
+from conftest import CASES, CF_CASES, OTHER_NP, load_case, load_cf_case
 from oracle import oracle as O
 
 
@@ -127,3 +127,46 @@ def test_tcsc_structure_matches_singlenode_harness():
     pairs = set(map(tuple, e[e[:, 0] != e[:, 1]])) | set((b, a) for a, b in map(tuple, e[e[:, 0] != e[:, 1]]))
     assert gb.nnz == len(pairs)
     assert gc.nnz == len(pairs) + len(set(map(tuple, e[e[:, 0] == e[:, 1]])))
+
+
+@pytest.mark.parametrize("name", CF_CASES)
+def test_tcsc_cf_format_is_the_references(name):
+    """The oracle's TCSC_CF restatement (source rows swapped to the tail of every column in the reference's swap order, the
+    four pair lists with their quirks) against the arrays dumped from the unmodified reference's compressor
+    (ds/compressed_column.hpp:603-1120; oracle/ref/dump_main.cpp -DAPP_TCSC_CF)."""
+    edges, nv, ref = load_cf_case(name)
+    g = O.OracleGraph(edges, nv, **O.APP_FLAGS["pr"])
+    assert (g.JA == ref["JA"]).all() and (g.JC == ref["JC"]).all() and (g.IR == ref["IR"]).all()
+    cf = g.tcsc_cf()
+    for k in ("IA", "JA_REG_R_NNZ_C"):
+        assert cf[k].shape == ref[k].shape and (cf[k] == ref[k]).all(), k
+    for l in g.CF_LISTS:
+        assert cf["NC_" + l] == int(ref["NC_" + l]), l
+        for k in ("JA_" + l, "JC_" + l):
+            assert cf[k].shape == ref[k].shape and (cf[k] == ref[k]).all(), k
+    # what the format promises: per column the same rows as TCSC, source rows last
+    src = ~np.isin(g.IR, g.JC)                       # compressed row -> its vertex has no column
+    for j in range(g.nnzcols):
+        a, b = g.JA[j], g.JA[j + 1]
+        assert sorted(cf["IA"][a:b]) == sorted(g.IA[a:b])
+        s = src[cf["IA"][a:b]]
+        assert not (s[:-1] & ~s[1:]).any()          # never a regular row after a source row
+    if name in ("rmat8", "rmat10", "rmat12", "mixed"):
+        assert (cf["IA"] != g.IA).any()              # the swap had work to do
+
+
+@pytest.mark.parametrize("name", CF_CASES)
+def test_tcsc_cf_spmv_adds_up_to_the_plain_spmv(name):
+    """vp:1243-1317 over the pair lists, all three conditions on, equals the TCSC SpMV whenever sink columns message 0
+    (they always do in PageRank: such a vertex has no row, hence degree 0 after initialize(other), vp:476-483)."""
+    edges, nv, _ = load_cf_case(name)
+    g = O.OracleGraph(edges, nv, **O.APP_FLAGS["pr"])
+    rng = np.random.RandomState(5)
+    x = rng.randint(1, 1000, g.nnzcols).astype(np.float64)
+    x[~np.isin(g.JC, g.IR)] = 0                      # sink columns
+    want = g.spmv_plus_f64(x, np.zeros(g.nnzrows))
+    got = g.spmv_cf_plus_f64(x, np.zeros(g.nnzrows), first=True, running=True, last=True)
+    assert (got == want).all()
+    src = ~np.isin(g.IR, g.JC)
+    part = g.spmv_cf_plus_f64(x, np.zeros(g.nnzrows), first=True, running=True, last=False)
+    assert (part[~src] == want[~src]).all() and (part[src] == 0).all()
