@@ -35,7 +35,8 @@ struct DevBuf {  // frees on scope exit: ingest scratch
 // ---- pass 1: per-record flags, global non-empty bitmaps, localisation -------------------
 // Order of the flag handling is the reference's (graph.hpp:337-356): drop self loop unless
 // self_loops; acyclic swap; transpose swap; insert; mirrored insert when !directed.
-__global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f,
+constexpr int EXPAND_TPB = 1024;
+__global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f,
                          uint32_t nrows, uint32_t perm_a, uint32_t perm_mask, uint32_t H, uint32_t row_lo, uint32_t row_hi,
                          uint64_t *__restrict__ keys, uint32_t *__restrict__ wts, uint64_t room /* capacity of keys / wts */,
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
@@ -48,10 +49,14 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
     // every segment are needed everywhere (the exchange layout numbers a source segment's columns by compressed id)
     const bool all_rows = (needby == nullptr);
     auto below = [](uint64_t mk) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0)); };
-    // COMPACTING: only the entries of this rank's tile-row are written (a rank of p sorts ~m/p keys, not m). A wave
-    // reserves room for what it keeps with one atomic; the order of the output is therefore arbitrary, which the sort
-    // that follows does not care about (equal keys -- and, with weights, equal (key, weight) pairs -- are interchangeable).
-    const uint64_t m64 = (m + 63) & ~63ull;
+    // COMPACTING: only the entries of this rank's tile-row are written (a rank of p sorts ~m/p keys, not m). A WORKGROUP
+    // reserves room for what it keeps with one atomic per round (one per wave was 16.7 M atomics on one address for R-MAT-26:
+    // 203 ms of kernel time, 26.5 ms with one per 1024 records -- profiles/r02_hubs_first/tilerow_ingest_kernels.txt); the order of the output is therefore arbitrary, which the sort that follows
+    // does not care about (equal keys -- and, with weights, equal (key, weight) pairs -- are interchangeable).
+    __shared__ uint32_t wave_kept[EXPAND_TPB / 64];
+    __shared__ unsigned long long round_base;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t m64 = (m + EXPAND_TPB - 1) / EXPAND_TPB * EXPAND_TPB;   // every thread of a workgroup makes the same number of rounds
     for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m64; e += (uint64_t)gridDim.x * blockDim.x) {
         bool keep0 = false, keep1 = false;
         uint64_t k0 = 0, k1 = 0;
@@ -66,8 +71,7 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
                 if (f.transpose) { uint32_t t = row; row = col; col = t; }
                 row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;   // internal ids (identity on one rank)
                 // test before set: a vertex has ~16 records on average, so 15 of 16 visits find the flag set and a cached read
-                // replaces a scattered one-byte write (read-modify-write of a sector at the memory side: 202 -> see DESIGN ms
-                // for a tile-row of 8 of R-MAT-26, whose hashed ids make every access random)
+                // replaces a scattered one-byte write (a read-modify-write of a sector at the memory side)
                 auto set = [](uint8_t *__restrict__ flags, uint64_t i) { if (!flags[i]) flags[i] = 1; };
                 if (all_rows || (row >= row_lo && row < row_hi)) set(rowflag, row);
                 set(colflag, col); glob++;
@@ -83,13 +87,20 @@ __global__ void k_expand(const uint32_t *__restrict__ rec, uint64_t m, int strid
         }
         const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
         const uint32_t n0 = (uint32_t)__popcll((unsigned long long)b0), n1 = (uint32_t)__popcll((unsigned long long)b1);
+        if (lane == 0) wave_kept[wave] = n0 + n1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (uint32_t v = 0; v < EXPAND_TPB / 64; v++) { const uint32_t c = wave_kept[v]; wave_kept[v] = total; total += c; }
+            round_base = total ? atomicAdd(&counters[0], (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
         if (n0 + n1) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)(n0 + n1));
-            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+            const unsigned long long base = round_base + wave_kept[wave];
             if (keep0) { const uint64_t o = base + below(b0); if (o < room) { keys[o] = k0; if (wts) wts[o] = w; } }
             if (keep1) { const uint64_t o = base + n0 + below(b1); if (o < room) { keys[o] = k1; if (wts) wts[o] = w; } }
         }
+        __syncthreads();   // wave_kept / round_base are rewritten by the next round
     }
     // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) { bad += __shfl_down(bad, o); glob += __shfl_down(glob, o); }
@@ -276,7 +287,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
 
     unsigned long long hc[3] = {0, 0, 0};
     for (int attempt = 0; attempt < 2 && m; attempt++) {
-        k_expand<<<grid_for(m), TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
+        k_expand<<<(unsigned)std::min<uint64_t>((m + EXPAND_TPB - 1) / EXPAND_TPB, 256u * 8u), EXPAND_TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
                                              multi ? needme.as<uint8_t>() : nullptr, multi ? needby.as<uint8_t>() : nullptr,

@@ -1,12 +1,47 @@
 #!/usr/bin/env python3
 """Times the four non-headline programs (BFS, CC, SSSP, Degree) on synthetic R-MAT on one GPU.
-GTEPS = stored entries x iterations / Execute time. Not a bench.py line: the BASELINE configs
-name these as parity cases; this script gives the numbers quoted in DESIGN.md.
+GTEPS = stored entries x iterations / Execute time -- the reference's convention, which counts entries the
+activity filter never touches. So for the min programs the line also carries a roofline figure on the bytes an iteration
+REQUIRES: with F_t the frontier (vertices whose state changed in the previous apply; iteration 0: the root, or every
+vertex for CC), E_t the stored entries of F_t's columns and D_t the vertices iteration t changes,
+    required_t = 4 E_t (row ids) + 8 |F_t| (column pointer + message) + 8 |D_t| (accumulator read + state write)
+(a lower bound: rows that are reached but do not change are not counted). `required_frac` = sum_t required_t / Execute time
+/ 8 TB/s; the frontier sizes come from an untimed second run stepped phase by phase. Not a bench.py line: the BASELINE
+configs name these as parity cases; this script gives the numbers quoted in DESIGN.md.
   python tools/bench_apps.py --scale 24 [--apps bfs,cc,sssp]"""
 import argparse, ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import graphtap_amd as gt
 from graphtap_amd import _lib
+
+
+def required_bytes(L, G, P, app):
+    """Steps the program again (scatter_gather / combine / apply) and returns (sum of required_t, per-iteration records)."""
+    t, i = G.tile(), G.info
+    JA = np.zeros(i.ncols_local + 1, np.uint32); JC = np.zeros(i.nnzcols, np.uint32)
+    _lib.check(L.gt_memcpy_d2h(JA.ctypes.data_as(C.c_void_p), t.JA, JA.nbytes)); _lib.check(L.gt_memcpy_d2h(JC.ctypes.data_as(C.c_void_p), t.JC, JC.nbytes))
+    outdeg = np.zeros(i.tile_height, np.int64); outdeg[JC] = np.diff(JA.astype(np.int64))[:i.nnzcols]
+    has_col = np.zeros(i.tile_height, bool); has_col[JC] = True
+    P.initialize()
+    h = P._handle()
+    key = {"bfs": "hops", "cc": "label", "sssp": "distance"}[app]
+    prev = P.V[key].copy()
+    frontier = has_col.copy() if app == "cc" else np.zeros(i.tile_height, bool)
+    if app != "cc": frontier[P.root] = True
+    total, per_it = 0, []
+    for _ in range(1000):
+        active = C.c_uint64()
+        _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 0, C.byref(active)))
+        cur = P.V[key]
+        changed = cur != prev
+        f = frontier & has_col
+        E, F, D = int(outdeg[f].sum()), int(f.sum()), int(changed.sum())
+        total += 4 * E + 8 * F + 8 * D
+        per_it.append({"frontier": F, "entries": E, "changed": D})
+        prev, frontier = cur.copy(), changed
+        if active.value == 0: break
+    return total, per_it
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=24)
@@ -41,8 +76,13 @@ for app in args.apps.split(","):
     P.execute(1 if app == "deg" else 0)
     st = P.stats
     cs = P.checksum(out=None)
+    extra = {}
+    if app != "deg":
+        req, per_it = required_bytes(L, G, P, app)
+        assert len(per_it) == st.iterations, (len(per_it), st.iterations)
+        extra = {"required_bytes": req, "required_GBps": req / st.seconds / 1e9, "required_frac": req / st.seconds / 8e12, "per_iteration": per_it}
     print(json.dumps({"app": app, "scale": scale, "edge_factor": args.edge_factor, "root": int(P.root), "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
                       "iterations": st.iterations, "sparse_iterations": int(st.spmspv_iterations), "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
                       "spmv_ms_mean": st.spmv_ms / max(st.spmv_launches, 1), "ingress_s": round(ingress, 3),
-                      "value_checksum": cs[0], "reachable": cs[1]}), flush=True)
+                      "value_checksum": cs[0], "reachable": cs[1], **extra}), flush=True)
     P.free(); G.free()

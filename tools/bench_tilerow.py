@@ -18,9 +18,12 @@ a = ap.parse_args()
 L = _lib.lib(); _lib.require_gpu(); _lib.check(L.gt_set_device(0))
 nv, m = 1 << a.scale, 16 << a.scale
 d = C.c_void_p(); _lib.check(L.gt_malloc(C.byref(d), m * 8)); _lib.check(L.gt_rmat_generate(d, a.scale, 1, 0, 0, m, None))
-_lib.check(L.gt_device_synchronize()); t_in = time.perf_counter()
-G = gt.Graph(); G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=a.rank, nranks=a.nranks)
-_lib.check(L.gt_device_synchronize()); t_in = time.perf_counter() - t_in   # ingest of this tile-row: TCSC build + layout + PB build
+def ingest():
+    _lib.check(L.gt_device_synchronize()); t = time.perf_counter()
+    G = gt.Graph(); G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=a.rank, nranks=a.nranks)
+    _lib.check(L.gt_device_synchronize()); return G, time.perf_counter() - t   # ingest of this tile-row: TCSC build + layout + PB build
+G, t_first = ingest(); G.free()   # the first build of a process also pays for the first hipMallocs of gigabytes and the code objects
+G, t_in = ingest()
 _lib.check(L.gt_free(d))
 V = gt.Deg_Program(G, True, False, False, gt._COL_); V.initialize()
 h = V._handle(); _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 1, None))
@@ -43,7 +46,7 @@ for _ in range(a.steps): step()
 _lib.check(L.gt_device_synchronize()); dt = time.perf_counter() - t0
 _lib.check(L.gt_program_timing(h, C.byref(ms), C.byref(n), 1))
 i = G.info
-print(json.dumps({"ingest_s": round(t_in, 4), "scale": a.scale, "rank": a.rank, "nranks": a.nranks, "x_slices": int(K), "sliced": bool(a.sliced), "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
+print(json.dumps({"ingest_s": round(t_in, 4), "ingest_first_s": round(t_first, 4), "scale": a.scale, "rank": a.rank, "nranks": a.nranks, "x_slices": int(K), "sliced": bool(a.sliced), "nnz_local": int(i.nnz_local), "nnzrows": int(i.nnzrows),
                   "seg_stride": int(i.seg_stride), "ms_per_step_compute_only": dt * 1e3 / a.steps, "spmv_ms": ms.value / max(n.value, 1),
                   "ncols_local": int(i.ncols_local), "recv_bytes_f32": int(sum(map(sum, G.exchange_plan()[3])) * 4),
                   "send_bytes_f32": int(i.send_elems * 4), "allgather_bytes_f32": int(i.nnzcols_global * 4)}))
