@@ -318,7 +318,11 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
         if (!verbose) return;
         (void)hipDeviceSynchronize();
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[build] %s: %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        gt_alloc_clock &c = gt_alloc_clock_ref();
+        fprintf(stderr, "[build] %s: %.1f ms (scratch: %llu hipMalloc %.1f ms, %.2f GB; %llu hipFree %.1f ms)\n", what,
+                std::chrono::duration<double, std::milli>(now - t).count(), (unsigned long long)c.mallocs, c.malloc_ms, c.bytes / 1e9,
+                (unsigned long long)c.frees, c.free_ms);
+        c = gt_alloc_clock{};
         t = now;
     };
     auto tb = std::chrono::steady_clock::now();

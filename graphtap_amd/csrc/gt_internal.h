@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,23 @@ void gt_set_error(const char *fmt, ...);
             return (status);                                                                \
         }                                                                                   \
     } while (0)
+
+// hipMalloc / hipFree of the build scratch, with the time they take (printed by the [build] lines of GRAPHTAP_PB_STATS)
+struct gt_alloc_clock { double malloc_ms = 0, free_ms = 0; uint64_t mallocs = 0, frees = 0, bytes = 0; };
+inline gt_alloc_clock &gt_alloc_clock_ref() { static gt_alloc_clock c; return c; }
+inline hipError_t gt_scratch_malloc(void **p, uint64_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    gt_alloc_clock &c = gt_alloc_clock_ref();
+    c.malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c.mallocs++; c.bytes += bytes;
+    return e;
+}
+inline void gt_scratch_free(void *p) {
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipFree(p);
+    gt_alloc_clock &c = gt_alloc_clock_ref();
+    c.free_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c.frees++;
+}
 
 // Owned tile-row of the reference's p x p grid, in HBM.
 struct gt_graph {

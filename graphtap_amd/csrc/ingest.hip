@@ -27,8 +27,8 @@ inline unsigned grid_for(uint64_t n, int per_thread = 1) {
 
 struct DevBuf {  // frees on scope exit: ingest scratch
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+    ~DevBuf() { if (p) gt_scratch_free(p); }
+    int alloc(uint64_t bytes) { return gt_scratch_malloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
     template <class T> T *as() { return (T *)p; }
 };
 
@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
                          uint32_t nrows, uint32_t perm_a, uint32_t perm_mask, uint32_t H, uint32_t row_lo, uint32_t row_hi,
                          uint64_t *__restrict__ keys, uint32_t *__restrict__ wts, uint64_t room /* capacity of keys / wts */,
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
-                         uint8_t *__restrict__ needme /* [span] columns this tile-row reads, or null on one rank */,
-                         uint8_t *__restrict__ needby /* [nranks][H] owned columns read by tile-row d, or null  */,
+                         uint32_t *__restrict__ needme /* [span] entries this tile-row has in every column, or null on one rank */,
+                         uint32_t *__restrict__ needby /* [nranks][H] entries tile-row d has in every owned column, or null */,
                          unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
     unsigned long long bad = 0, glob = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -75,13 +75,15 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
                 auto set = [](uint8_t *__restrict__ flags, uint64_t i) { if (!flags[i]) flags[i] = 1; };
                 if (all_rows || (row >= row_lo && row < row_hi)) set(rowflag, row);
                 set(colflag, col); glob++;
-                if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; keep0 = true; if (needme) set(needme, col); }
-                if (needby && col >= row_lo && col < row_hi) set(needby, (uint64_t)(row / H) * H + (col - row_lo));
+                // counts, not flags: both sides of an exchange block order its columns by these (descending), so the receiver's
+                // count of column c and the owner's count for that receiver must come from the same records -- they do
+                if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; keep0 = true; if (needme) atomicAdd(&needme[col], 1u); }
+                if (needby && col >= row_lo && col < row_hi) atomicAdd(&needby[(uint64_t)(row / H) * H + (col - row_lo)], 1u);
                 if (!f.directed) {
                     if (all_rows || (col >= row_lo && col < row_hi)) set(rowflag, col);
                     set(colflag, row); glob++;
-                    if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; keep1 = true; if (needme) set(needme, row); }
-                    if (needby && row >= row_lo && row < row_hi) set(needby, (uint64_t)(col / H) * H + (row - row_lo));
+                    if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; keep1 = true; if (needme) atomicAdd(&needme[row], 1u); }
+                    if (needby && row >= row_lo && row < row_hi) atomicAdd(&needby[(uint64_t)(col / H) * H + (row - row_lo)], 1u);
                 }
             }
         }
@@ -113,27 +115,67 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
 struct U8ToU32 {
     __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; }
 };
+struct NonZero {
+    __host__ __device__ uint32_t operator()(const uint32_t &v) const { return v ? 1u : 0u; }
+};
 
 // ---- several ranks: the column space of a tile-row is LOCAL. Rank r keeps only the columns its tile-row has an
 // entry in ("needed" columns, ~47 % of all non-empty columns at p = 8 on R-MAT-26), ordered [slice k][source segment s]
 // [ascending compressed column j]; slice of a column = j / T. Block (k, s) is what rank s sends to rank r in the k-th
 // all-to-all of an iteration, so the receive buffer of that collective IS slice k of the SpMV's message vector.
+// INSIDE a block the columns are ordered by the number of entries the receiving tile-row has in them, descending (ties:
+// ascending column): the phase-1 windows at the head of every block then hold its hub columns, whose same-row entries
+// pre-aggregate several times better (pb.hip) -- the hubs-first layout of the single-rank build, block by block, at no
+// cost at run time because the sender packs its buffer through an index list anyway (k_pack_send). `Pneed[col]` is that
+// position; the owner computes the same order from the same counts (k_send_list, Pby).
 struct BlockTab { uint32_t clo, sneed_lo, base; };   // first internal column id of block (k,s); Sneed there; first local id
 
 __device__ __forceinline__ uint32_t local_col(const BlockTab *__restrict__ tab, const uint32_t *__restrict__ Scol,
-                                              const uint32_t *__restrict__ Sneed, uint32_t H, uint32_t T, uint32_t p, uint32_t col) {
+                                              const uint32_t *__restrict__ Pneed, uint32_t H, uint32_t T, uint32_t p, uint32_t col) {
     const uint32_t seg = col / H, j = Scol[col] - Scol[seg * H], k = j / T;
-    const BlockTab b = tab[k * p + seg];
-    return b.base + (Sneed[col] - b.sneed_lo);
+    return tab[k * p + seg].base + Pneed[col];
+}
+
+// sort keys of the needed columns / of the (destination, owned column) pairs: (block, entries descending); the radix sort is
+// stable and the items arrive in ascending column order
+__global__ void k_need_keys(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ Sneed, uint64_t span, const uint32_t *__restrict__ Scol,
+                            uint32_t H, uint32_t T, uint32_t p, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+    for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t n = cnt[c];
+        if (!n) continue;
+        const uint32_t seg = (uint32_t)(c / H), j = Scol[c] - Scol[(uint64_t)seg * H], k = j / T;
+        const uint32_t o = Sneed[c];
+        key[o] = ((uint64_t)(k * p + seg) << 32) | (0xFFFFFFFFu - n);
+        val[o] = (uint32_t)c;
+    }
+}
+__global__ void k_by_keys(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ Sby, uint32_t H, uint32_t T, uint32_t p,
+                          const uint32_t *__restrict__ Scol, uint32_t col_lo, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+    const uint64_t n_all = (uint64_t)p * H;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_all; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t n = cnt[t];
+        if (!n) continue;
+        const uint32_t d = (uint32_t)(t / H), i = (uint32_t)(t - (uint64_t)d * H);
+        const uint32_t j = Scol[col_lo + i] - Scol[col_lo], k = j / T;
+        const uint32_t o = Sby[t];
+        key[o] = ((uint64_t)(k * p + d) << 32) | (0xFFFFFFFFu - n);
+        val[o] = (uint32_t)t;
+    }
+}
+// position of every sorted item inside its block: sorted index - first sorted index of the block
+__global__ void k_block_positions(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint32_t n,
+                                  const uint32_t *__restrict__ block_start, uint32_t *__restrict__ P) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        P[val[i]] = i - block_start[(uint32_t)(key[i] >> 32)];
 }
 
 // Done BEFORE the sort so that the entries come out ordered by the id the kernels use.
-__global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ Scol, const uint32_t *__restrict__ Sneed,
+__global__ void k_remap_cols(uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ Scol, const uint32_t *__restrict__ Pneed,
                              const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[i];
         const uint32_t col = (uint32_t)(k >> 32);
-        const uint32_t c = tab ? local_col(tab, Scol, Sneed, H, T, p, col) : Scol[col];   // one rank: the compressed column id
+        const uint32_t c = tab ? local_col(tab, Scol, Pneed, H, T, p, col) : Scol[col];   // one rank: the compressed column id
         keys[i] = ((uint64_t)c << 32) | (uint32_t)k;
     }
 }
@@ -155,18 +197,18 @@ __global__ void k_gather_u32(const uint32_t *__restrict__ src, const uint64_t *_
     if (t < n) out[t] = src[idx[t]];
 }
 // local column -> slot of the global [segment][seg_stride] column space (Degree in _COL_ order all-reduces there)
-__global__ void k_local_to_global(const uint8_t *__restrict__ needme, uint64_t span, const uint32_t *__restrict__ Scol,
-                                  const uint32_t *__restrict__ Sneed, const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p,
+__global__ void k_local_to_global(const uint32_t *__restrict__ needme, uint64_t span, const uint32_t *__restrict__ Scol,
+                                  const uint32_t *__restrict__ Pneed, const BlockTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p,
                                   uint32_t S, uint32_t *__restrict__ loc2glob) {
     for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
         if (!needme[c]) continue;
         const uint32_t seg = (uint32_t)(c / H);
-        loc2glob[local_col(tab, Scol, Sneed, H, T, p, (uint32_t)c)] = seg * S + (Scol[c] - Scol[(uint64_t)seg * H]);
+        loc2glob[local_col(tab, Scol, Pneed, H, T, p, (uint32_t)c)] = seg * S + (Scol[c] - Scol[(uint64_t)seg * H]);
     }
 }
 // send list: element i of the send buffer is the message of owned compressed column send_idx[i]
 struct SendTab { uint32_t sby_lo, base; };   // Sby at the first column of block (k,d); first send-buffer element of the block
-__global__ void k_send_list(const uint8_t *__restrict__ needby, const uint32_t *__restrict__ Sby, const uint32_t *__restrict__ Scol,
+__global__ void k_send_list(const uint32_t *__restrict__ needby, const uint32_t *__restrict__ Pby, const uint32_t *__restrict__ Scol,
                             const SendTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p, uint32_t col_lo, uint32_t *__restrict__ send_idx) {
     const uint64_t n = (uint64_t)p * H;
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -174,7 +216,7 @@ __global__ void k_send_list(const uint8_t *__restrict__ needby, const uint32_t *
         const uint32_t d = (uint32_t)(t / H), i = (uint32_t)(t - (uint64_t)d * H);
         const uint32_t j = Scol[col_lo + i] - Scol[col_lo], k = j / T;
         const SendTab b = tab[k * p + d];
-        send_idx[b.base + (Sby[t] - b.sby_lo)] = j;
+        send_idx[b.base + Pby[t]] = j;
     }
 }
 
@@ -265,7 +307,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     // runs on a one-GPU box
     const bool multi = p > 1 || g->force_exchange;
 
-    DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby;
+    DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby, Pneed, Pby;
     // Room for the kept entries: everything on one rank; on several, the hashed id space spreads the entries evenly, so
     // 1.25 x the mean share (+ slack for small graphs) is reserved and the pass is repeated with the exact count in the
     // rare case it does not fit (a multi-GB hipMalloc is not free: 8.6 GB for every rank of 8 at R-MAT-26 otherwise).
@@ -279,10 +321,11 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
     ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
     if (multi) {
-        ING_ALLOC(needme, span + 1); ING_ALLOC(needby, span + 1);
+        ING_ALLOC(needme, (span + 1) * 4); ING_ALLOC(needby, (span + 1) * 4);
         ING_ALLOC(Sneed, (span + 1) * 4); ING_ALLOC(Sby, (span + 1) * 4);
-        ING_HIP(hipMemsetAsync(needme.p, 0, span + 1, s));
-        ING_HIP(hipMemsetAsync(needby.p, 0, span + 1, s));
+        ING_ALLOC(Pneed, (span + 1) * 4); ING_ALLOC(Pby, (span + 1) * 4);
+        ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s));
+        ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s));
     }
 
     unsigned long long hc[3] = {0, 0, 0};
@@ -290,15 +333,16 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         k_expand<<<(unsigned)std::min<uint64_t>((m + EXPAND_TPB - 1) / EXPAND_TPB, 256u * 8u), EXPAND_TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
-                                             multi ? needme.as<uint8_t>() : nullptr, multi ? needby.as<uint8_t>() : nullptr,
+                                             multi ? needme.as<uint32_t>() : nullptr, multi ? needby.as<uint32_t>() : nullptr,
                                              counters.as<unsigned long long>());
         ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
         ING_HIP(hipStreamSynchronize(s));
         if (hc[0] <= room) break;
-        // did not fit (nothing was written past `room`): exact size, second pass (flags are idempotent)
+        // did not fit (nothing was written past `room`): exact size, second pass (flags are idempotent, the counts start over)
+        if (multi) { ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s)); ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s)); }
         room = hc[0];
-        (void)hipFree(keys.p); keys.p = nullptr; ING_ALLOC(keys, room * 8);
-        if (weighted) { (void)hipFree(wts.p); wts.p = nullptr; ING_ALLOC(wts, room * 4); }
+        gt_scratch_free(keys.p); keys.p = nullptr; ING_ALLOC(keys, room * 8);
+        if (weighted) { gt_scratch_free(wts.p); wts.p = nullptr; ING_ALLOC(wts, room * 4); }
         ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
     }
     if (hc[1]) {
@@ -321,8 +365,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, rin, Srow.as<uint32_t>(), span + 1, s));
         ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, cin, Scol.as<uint32_t>(), span + 1, s));
         if (multi) {
-            hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> nin(needme.as<const uint8_t>(), U8ToU32());
-            hipcub::TransformInputIterator<uint32_t, U8ToU32, const uint8_t *> bin(needby.as<const uint8_t>(), U8ToU32());
+            hipcub::TransformInputIterator<uint32_t, NonZero, const uint32_t *> nin(needme.as<const uint32_t>(), NonZero());
+            hipcub::TransformInputIterator<uint32_t, NonZero, const uint32_t *> bin(needby.as<const uint32_t>(), NonZero());
             ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, nin, Sneed.as<uint32_t>(), span + 1, s));
             ING_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, bin, Sby.as<uint32_t>(), span + 1, s));
         }
@@ -404,6 +448,41 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         g->recv_off[K] = xo; g->send_off[K] = so;
         g->ncols_total = (uint32_t)xo;
         g->send_elems = so;
+        // positions inside the blocks: one stable sort of the needed columns by (block, entries descending), one of the
+        // (destination, owned column) pairs; block b = k * p + q starts where the blocks before it (in b order) end
+        {
+            const uint32_t nblk = K * p;
+            std::vector<uint32_t> start_me(nblk + 1, 0), start_by(nblk + 1, 0);
+            for (uint32_t b = 0; b < nblk; b++) {   // b = kk * p + q, the order of the sort key
+                start_me[b + 1] = start_me[b] + (sneed_at[b + p] - sneed_at[b]);
+                start_by[b + 1] = start_by[b] + (sby_at[b + p] - sby_at[b]);
+            }
+            const uint32_t n_me = start_me[nblk], n_by = start_by[nblk];
+            DevBuf k1, k2, v1, v2, st_d, srt;
+            const uint32_t nmax = std::max(std::max(n_me, n_by), 1u);
+            ING_ALLOC(k1, (uint64_t)nmax * 8); ING_ALLOC(k2, (uint64_t)nmax * 8); ING_ALLOC(v1, (uint64_t)nmax * 4); ING_ALLOC(v2, (uint64_t)nmax * 4);
+            ING_ALLOC(st_d, (uint64_t)(nblk + 1) * 4);
+            size_t tb = 0;
+            {
+                hipcub::DoubleBuffer<uint64_t> dk(k1.as<uint64_t>(), k2.as<uint64_t>());
+                hipcub::DoubleBuffer<uint32_t> dv(v1.as<uint32_t>(), v2.as<uint32_t>());
+                ING_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dv, nmax, 0, 48, s));
+            }
+            ING_ALLOC(srt, tb);
+            for (int side = 0; side < 2; side++) {
+                const uint32_t n = side ? n_by : n_me;
+                if (!n) continue;
+                if (side == 0) k_need_keys<<<grid_for(span), TPB, 0, s>>>(needme.as<uint32_t>(), Sneed.as<uint32_t>(), span, Scol.as<uint32_t>(), H, T, p, k1.as<uint64_t>(), v1.as<uint32_t>());
+                else k_by_keys<<<grid_for(span), TPB, 0, s>>>(needby.as<uint32_t>(), Sby.as<uint32_t>(), H, T, p, Scol.as<uint32_t>(), row_lo, k1.as<uint64_t>(), v1.as<uint32_t>());
+                hipcub::DoubleBuffer<uint64_t> dk(k1.as<uint64_t>(), k2.as<uint64_t>());
+                hipcub::DoubleBuffer<uint32_t> dv(v1.as<uint32_t>(), v2.as<uint32_t>());
+                size_t tb2 = tb;
+                ING_HIP(hipcub::DeviceRadixSort::SortPairs(srt.p, tb2, dk, dv, n, 0, 48, s));
+                ING_HIP(hipMemcpyAsync(st_d.p, (side ? start_by : start_me).data(), (uint64_t)(nblk + 1) * 4, hipMemcpyHostToDevice, s));
+                k_block_positions<<<grid_for(n), TPB, 0, s>>>(dk.Current(), dv.Current(), n, st_d.as<uint32_t>(), (side ? Pby : Pneed).as<uint32_t>());
+                ING_HIP(hipStreamSynchronize(s));   // the host vectors and the double buffers are reused by the other side
+            }
+        }
         ING_ALLOC(rtab_d, rtab.size() * sizeof(BlockTab));
         ING_HIP(hipMemcpyAsync(rtab_d.p, rtab.data(), rtab.size() * sizeof(BlockTab), hipMemcpyHostToDevice, s));
         DevBuf stab_d;
@@ -416,16 +495,16 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         }
         ING_HIP(hipMemsetAsync(g->loc2glob, 0xFF, (uint64_t)g->ncols_total * 4, s));
         ING_HIP(hipMemsetAsync(g->send_idx, 0, std::max<uint64_t>(so, 1) * 4, s));
-        k_local_to_global<<<grid_for(span), TPB, 0, s>>>(needme.as<uint8_t>(), span, Scol.as<uint32_t>(), Sneed.as<uint32_t>(),
+        k_local_to_global<<<grid_for(span), TPB, 0, s>>>(needme.as<uint32_t>(), span, Scol.as<uint32_t>(), Pneed.as<uint32_t>(),
                                                          rtab_d.as<BlockTab>(), H, T, p, seg_stride, g->loc2glob);
-        k_send_list<<<grid_for(span), TPB, 0, s>>>(needby.as<uint8_t>(), Sby.as<uint32_t>(), Scol.as<uint32_t>(), stab_d.as<SendTab>(),
+        k_send_list<<<grid_for(span), TPB, 0, s>>>(needby.as<uint32_t>(), Pby.as<uint32_t>(), Scol.as<uint32_t>(), stab_d.as<SendTab>(),
                                                    H, T, p, row_lo, g->send_idx);
         ING_HIP(hipStreamSynchronize(s));   // stab / idx scratch go out of scope here
     }
     g->info.ncols_local = g->ncols_total;
     g->info.send_elems = (uint32_t)g->send_elems;
 
-    if (nvalid) k_remap_cols<<<grid_for(nvalid), TPB, 0, s>>>(keys.as<uint64_t>(), nvalid, Scol.as<uint32_t>(), multi ? Sneed.as<uint32_t>() : nullptr,
+    if (nvalid) k_remap_cols<<<grid_for(nvalid), TPB, 0, s>>>(keys.as<uint64_t>(), nvalid, Scol.as<uint32_t>(), multi ? Pneed.as<uint32_t>() : nullptr,
                                                         multi ? rtab_d.as<BlockTab>() : nullptr, H, T, p);
     // column-major order (ColSort, ds/triple.hpp:78-98): (col,row); with weights (col,row,weight)
     // so that the first copy of a duplicate (row,col) carries its minimum weight. Only the nvalid kept

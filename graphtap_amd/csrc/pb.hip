@@ -95,8 +95,8 @@ inline unsigned grid_for(uint64_t n) {
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+    ~DevBuf() { if (p) gt_scratch_free(p); }
+    int alloc(uint64_t bytes) { return gt_scratch_malloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
     template <class T> T *as() { return (T *)p; }
 };
 

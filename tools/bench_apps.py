@@ -32,13 +32,16 @@ def required_bytes(L, G, P, app):
     total, per_it = 0, []
     for _ in range(1000):
         active = C.c_uint64()
-        _lib.check(L.gt_program_scatter_gather(h)); _lib.check(L.gt_program_combine(h)); _lib.check(L.gt_program_apply(h, 0, C.byref(active)))
+        ms = []
+        for call in (lambda: L.gt_program_scatter_gather(h), lambda: L.gt_program_combine(h), lambda: L.gt_program_apply(h, 0, C.byref(active))):
+            _lib.check(L.gt_device_synchronize()); t0 = time.perf_counter()
+            _lib.check(call()); _lib.check(L.gt_device_synchronize()); ms.append(round((time.perf_counter() - t0) * 1e3, 3))
         cur = P.V[key]
         changed = cur != prev
         f = frontier & has_col
         E, F, D = int(outdeg[f].sum()), int(f.sum()), int(changed.sum())
         total += 4 * E + 8 * F + 8 * D
-        per_it.append({"frontier": F, "entries": E, "changed": D})
+        per_it.append({"frontier": F, "entries": E, "changed": D, "stepped_ms": ms})   # scatter_gather, combine, apply with a sync after each
         prev, frontier = cur.copy(), changed
         if active.value == 0: break
     return total, per_it
