@@ -214,7 +214,7 @@ inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv
 
 // kernels.hip
 // Frontier-driven SpMSpV of the min semirings (the reference's sparse path, vp:754-784 and 1475-1489): y[r] = min(y[r], x[c] (+ w))
-// over the entries of the ACTIVE columns only. Counts first; runs only if they hold at most nnz / 4096 entries (or GRAPHTAP_SPMSPV
+// over the entries of the ACTIVE columns only. Counts first; runs only if they hold at most nnz / 1024 entries (or GRAPHTAP_SPMSPV
 // forces it); *done tells whether the SpMV is complete.
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);

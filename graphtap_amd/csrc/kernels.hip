@@ -121,24 +121,39 @@ __global__ void k_frontier_count(const uint32_t *__restrict__ x, uint32_t x_len,
         n++; e += JA[c + 1] - JA[c];
     }
     for (int o = 32; o > 0; o >>= 1) { n += __shfl_down(n, o); e += __shfl_down(e, o); }
-    if ((threadIdx.x & 63) == 0 && n) { atomicAdd(&out[0], n); atomicAdd(&out[1], e); }
+    __shared__ unsigned long long part[2][TPB / 64];   // one pair of atomics per workgroup: they all hit the same two words
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = n; part[1][threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; w++) { n += part[0][w]; e += part[1][w]; }
+        if (n) { atomicAdd(&out[0], n); atomicAdd(&out[1], e); }
+    }
 }
-__global__ void k_frontier_list(const uint32_t *__restrict__ x, uint32_t x_len, const uint32_t *__restrict__ xcol, const uint32_t *__restrict__ JA,
+__global__ void __launch_bounds__(TPB) k_frontier_list(const uint32_t *__restrict__ x, uint32_t x_len, const uint32_t *__restrict__ xcol, const uint32_t *__restrict__ JA,
                                 unsigned int *__restrict__ cursor, uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg) {
-    const uint32_t n64 = (x_len + 63) & ~63u, lane = threadIdx.x & 63;
-    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n64; sl += gridDim.x * blockDim.x) {
+    // one reservation per WORKGROUP and round: every reservation hits the same word, and one per wave is 0.5 M of them on a
+    // 33 M-slot x (5 ms by itself once most waves hold an active column)
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned round_base;
+    const uint32_t n_round = (x_len + TPB - 1) / TPB * TPB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n_round; sl += gridDim.x * blockDim.x) {
         uint32_t c = 0xFFFFFFFFu, v = GT_INF;
         if (sl < x_len) { v = x[sl]; if (v != GT_INF) c = xcol ? xcol[sl] : sl; }
         const bool act = c != 0xFFFFFFFFu;
         const uint64_t b = __ballot(act);
-        if (!b) continue;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned)__popcll((unsigned long long)b));
-        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane == 0) wave_n[wave] = (unsigned)__popcll((unsigned long long)b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+            round_base = total ? atomicAdd(cursor, total) : 0u;
+        }
+        __syncthreads();
         if (act) {
-            const uint32_t o = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            const uint32_t o = round_base + wave_n[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
             col[o] = c; val[o] = v; deg[o] = JA[c + 1] - JA[c];
         }
+        __syncthreads();   // wave_n / round_base are rewritten by the next round
     }
 }
 // one thread per entry of an active column: the column is found by bisection of the entry offsets
@@ -186,7 +201,8 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     const bool force = env && atoi(env) == 1;
     // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
     // count the converge-mode driver reads anyway) activated few vertices
-    if (!force && p->last_active > 16384) return GT_OK;
+    static const uint64_t max_active = getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE")) : 16384;
+    if (!force && p->last_active > max_active) return GT_OK;
     if (!p->d_frontier) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
     GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
     const uint32_t x_len = (uint32_t)p->x_elems;
@@ -197,10 +213,12 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     GT_HIP(hipStreamSynchronize(s));
     if (h[0] == 0 || h[1] == 0) { *done = true; return GT_OK; }  // empty frontier (or active columns without entries here): y keeps its running minima
     // The reference switches at 0.6 of the columns (vp:769). Here the streaming pass already skips every window without an
-    // active column (pb.hip), so the frontier-driven kernel only pays for tiny frontiers -- measured on BFS / CC / SSSP of
-    // R-MAT-26: at <= nnz/64 entries 5 of 7 BFS iterations took it and the run was 37 % SLOWER (18.3 vs 13.3 ms; count +
-    // compaction + scan + device atomics against a pass that exits at once on idle windows) -- hence the low default.
-    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 4096;
+    // active column (pb.hip), so the frontier-driven kernel only pays for small frontiers -- measured on BFS / CC / SSSP of
+    // R-MAT-26 (tools/spmspv_sweep.sh, profiles/r02_hubs_first/spmspv_sweep.txt): 4.7 M entries of 3.7 M columns take it
+    // 1.6 ms against 1.0 ms for the streaming pass; the ONE hub column of iteration 0 (1 M entries, nnz / 2000) takes it
+    // 0.17 against 1.5 ms, because that column's window is the heaviest of all. Hence: at most nnz / 1024 entries, and the
+    // frontier is only counted when the previous apply activated <= 16 384 vertices.
+    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 1024;
     if (!force && h[1] > nnz / frac) return GT_OK;
     GT_REQUIRE(h[0] < 0xFFFFFFFFull && h[1] < (1ull << 40), GT_ERR_UNSUPPORTED, "frontier too large for the sparse path");
     const uint32_t nact = (uint32_t)h[0];
