@@ -168,14 +168,32 @@ __global__ void k_source_bits(const uint32_t *__restrict__ R2C, uint32_t nr, uin
         if ((threadIdx.x & 63) == 0) { bits[r >> 5] = (uint32_t)b; bits[(r >> 5) + 1] = (uint32_t)(b >> 32); }
     }
 }
+// Histogram of per-entry keys whose neighbours mostly agree (the entries arrive column-major with ascending rows: a wave's 64
+// consecutive entries share the column, hence the window, and almost always the row bin): every maximal run of equal keys
+// inside a wave does ONE atomic with its length. `key` = ~0u: not counted. All 64 lanes must call.
+__device__ __forceinline__ void wave_run_add(uint32_t *__restrict__ counters, uint32_t key, uint32_t lane) {
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || key != prev;
+    const uint64_t heads = __ballot(head);
+    if (head && key != 0xFFFFFFFFu) {
+        const uint64_t later = lane == 63 ? 0ull : (heads >> (lane + 1));   // heads after this lane
+        const uint32_t len = later ? (uint32_t)__builtin_ctzll((unsigned long long)later) + 1u : 64u - lane;
+        atomicAdd(&counters[key], len);
+    }
+}
 // moves the entries of source rows from their window's count to the class-1 copy of the window
 __global__ void k_win_count_src(const uint32_t *__restrict__ JI, const uint32_t *__restrict__ IA, uint64_t nnz, const uint32_t *__restrict__ xslot,
-                                WinGeom geom, const uint32_t *__restrict__ srcbits, uint32_t *__restrict__ wcount) {
-    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * blockDim.x) {
-        if (!row_class(srcbits, IA[e])) continue;
-        const uint32_t q = win_of(geom, slot_of(xslot, JI[e]));
-        atomicSub(&wcount[q], 1u); atomicAdd(&wcount[geom.nwin + q], 1u);
+                                WinGeom geom, const uint32_t *__restrict__ srcbits, uint32_t *__restrict__ wcount_src /* wcount + nwin */) {
+    const uint64_t n64 = (nnz + 63) & ~63ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n64; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (e < nnz && row_class(srcbits, IA[e])) key = win_of(geom, slot_of(xslot, JI[e]));
+        wave_run_add(wcount_src, key, lane);
     }
+}
+__global__ void k_win_count_move(uint32_t *__restrict__ wcount, uint32_t nwin) {   // class 0 keeps what class 1 did not take
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x) wcount[q] -= wcount[nwin + q];
 }
 // A window (dense: W slots, sparse: WS slots) is one chunk, unless it holds more than `ch` entries: such a window is cut into
 // several chunks by ROW BIN -- consecutive bins are packed into chunks of ~n/ceil(n/ch) entries, so every run holds
@@ -191,13 +209,20 @@ __global__ void k_win_sizes(const uint32_t *__restrict__ wcount, uint32_t nwin, 
         cutflag[q] = (n > ch) ? 1u : 0u;
     }
 }
-// entries of every cut window per row bin, counted into plan[]
+// entries of every cut window per row bin, counted into plan[] (one atomic per run of equal (window, bin) inside a wave: per
+// entry it was 0.31 s for R-MAT-26 -- the counters of hub windows x hub bins take hundreds of thousands of increments each)
 __global__ void k_win_hist(const uint32_t *__restrict__ JI, const uint32_t *__restrict__ IA, uint64_t nnz, const uint32_t *__restrict__ xslot, WinGeom geom,
                            const uint32_t *__restrict__ srcbits, uint32_t nbins, const uint32_t *__restrict__ cutflag, const uint32_t *__restrict__ cutidx,
                            uint32_t *__restrict__ plan) {
-    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t q = row_class(srcbits, IA[e]) * geom.nwin + win_of(geom, slot_of(xslot, JI[e]));
-        if (cutflag[q]) atomicAdd(&plan[(uint64_t)cutidx[q] * nbins + (IA[e] >> RB)], 1u);
+    const uint64_t n64 = (nnz + 63) & ~63ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n64; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (e < nnz) {
+            const uint32_t r = IA[e], q = row_class(srcbits, r) * geom.nwin + win_of(geom, slot_of(xslot, JI[e]));
+            if (cutflag[q]) key = cutidx[q] * nbins + (r >> RB);
+        }
+        wave_run_add(plan, key, lane);
     }
 }
 // counts -> plan, in place; one thread per cut window (a few thousand bins each)
@@ -917,7 +942,10 @@ int gt_pb_build(gt_graph *g) {
     PB_ALLOC(cutflag, (uint64_t)(nwin + 1) * 4); PB_ALLOC(cutidx, (uint64_t)(nwin + 1) * 4);
     PB_HIP(hipMemsetAsync(wcount.p, 0, (uint64_t)(nwin + 1) * 4, s));
     k_win_count<<<grid_for(ncols), TPB, 0, s>>>(g->JA, ncols, g->xslot, geom, wcount.as<uint32_t>());
-    if (classes) k_win_count_src<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, srcbits, wcount.as<uint32_t>());
+    if (classes) {
+        k_win_count_src<<<grid_for(nnz), TPB, 0, s>>>(g->JI, g->IA, nnz, g->xslot, geom, srcbits, wcount.as<uint32_t>() + geom.nwin);
+        k_win_count_move<<<grid_for(geom.nwin), TPB, 0, s>>>(wcount.as<uint32_t>(), geom.nwin);
+    }
     uint32_t nchunks = 0;
     for (;;) {  // chunk ids must fit above the bin bits of a 32-bit sort key
         PB_HIP(hipMemsetAsync(nsub.p, 0, (uint64_t)(nwin + 1) * 4, s));
@@ -926,7 +954,8 @@ int gt_pb_build(gt_graph *g) {
         PB_SCAN_EXCL(cutflag.as<uint32_t>(), cutidx.as<uint32_t>(), nwin + 1);
         uint32_t ncut = 0;
         PB_HIP(hipMemcpy(&ncut, cutidx.as<uint32_t>() + nwin, 4, hipMemcpyDeviceToHost));
-        if (plan.p) { (void)hipFree(plan.p); plan.p = nullptr; }
+        if (plan.p) { gt_scratch_free(plan.p); plan.p = nullptr; }
+        GT_REQUIRE((uint64_t)std::max(ncut, 1u) * pb->nbins < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "%u heavy windows x %u row bins: the chunk plan exceeds 32-bit indexing", ncut, pb->nbins);
         PB_ALLOC(plan, (uint64_t)std::max(ncut, 1u) * pb->nbins * 4);
         if (ncut) {
             PB_HIP(hipMemsetAsync(plan.p, 0, (uint64_t)ncut * pb->nbins * 4, s));
