@@ -60,24 +60,6 @@ __global__ void k_msg_min(uint32_t *__restrict__ x, const uint32_t *__restrict__
     }
 }
 
-// The same under the hubs-first layout, where slot order is not vertex order: the changed flags are read from Cx, their copy in
-// SLOT order (apply sets it through the row -> slot map), so that the pass reads one byte per slot in sequence and touches a
-// vertex only where it is active -- C[XV[j]] was a random byte gather per slot (0.19 -> 0.06 ms on the 33 M slots of R-MAT-26).
-__global__ void k_msg_min_cx(uint32_t *__restrict__ x, const uint32_t *__restrict__ XV, uint32_t n, const uint8_t *__restrict__ Cx,
-                             const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        uint32_t m = GT_INF;
-        if (Cx[j]) { const uint32_t v = XV[j]; m = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]; }
-        x[j] = m;
-    }
-}
-__global__ void k_cx_init(uint8_t *__restrict__ Cx, const uint32_t *__restrict__ XV, uint32_t n, const uint8_t *__restrict__ C) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t v = XV[j];
-        Cx[j] = (v != 0xFFFFFFFFu) ? C[v] : 0;
-    }
-}
-
 // Deg in _COL_ order (apps/pr.cpp:40-42; vp:1174-1184 with x == 1): y[c] = entries in column c. Several ranks: the
 // tile-row's local columns scatter into the global [segment][seg_stride] space (zero-filled by the caller).
 __global__ void k_col_counts(const uint32_t *__restrict__ JA, uint32_t ncols, const uint32_t *__restrict__ loc2glob, uint32_t *__restrict__ y) {
@@ -184,20 +166,18 @@ __global__ void k_pr_cf_tail_c(const uint32_t *__restrict__ R2C, uint32_t nr, do
 }
 __global__ void k_apply_bfs(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
                             uint32_t *__restrict__ parent, uint32_t *__restrict__ hops, uint8_t *__restrict__ C,
-                            uint32_t iteration, unsigned long long *d_active, uint8_t *__restrict__ Cx, const uint32_t *__restrict__ R2X) {
+                            uint32_t iteration, unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
         uint32_t v = IR[r], yv = y[r];
         uint8_t c = 0;  // bfs.h:65-77
         if (hops[v] == GT_INF && yv != GT_INF) { hops[v] = iteration + 1; parent[v] = yv; c = 1; }
         C[v] = c; act += c;
-        if (c && Cx) { const uint32_t sl = R2X[r]; if (sl != 0xFFFFFFFFu) Cx[sl] = 1; }   // zero-filled by the caller
     }
     count_active(act, d_active);
 }
 __global__ void k_apply_min(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
-                            uint32_t *__restrict__ s0, uint8_t *__restrict__ C, unsigned long long *d_active,
-                            uint8_t *__restrict__ Cx, const uint32_t *__restrict__ R2X) {
+                            uint32_t *__restrict__ s0, uint8_t *__restrict__ C, unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
         uint32_t v = IR[r], yv = y[r], tmp = s0[v];  // sssp.h:57-65 (HAS_WEIGHT), cc.h:51-55
@@ -205,7 +185,6 @@ __global__ void k_apply_min(const uint32_t *__restrict__ y, const uint32_t *__re
         s0[v] = nv;
         uint8_t c = (nv != tmp);
         C[v] = c; act += c;
-        if (c && Cx) { const uint32_t sl = R2X[r]; if (sl != 0xFFFFFFFFu) Cx[sl] = 1; }
     }
     count_active(act, d_active);
 }
@@ -438,7 +417,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->Cx, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -478,7 +457,6 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
-    if (ok && !p->stationary && g->XV && g->R2X) ok = hipMalloc((void **)&p->Cx, std::max<uint64_t>(g->x_len, 1)) == hipSuccess;   // hubs-first layout
     if (ok && prm->kind == GT_PR) {
         const uint64_t nr = std::max<uint32_t>(g->info.nnzrows, 1);
         ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess && hipMalloc((void **)&p->rank_c, nr * 8) == hipSuccess &&
@@ -536,7 +514,6 @@ static int init_common(gt_program *p) {
             break;
         default:
             k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
-            if (p->Cx) k_cx_init<<<grid_for(g->x_len), TPB, 0, s>>>(p->Cx, g->XV, g->x_len, p->C);
             break;
     }
     // messages: padding columns are never referenced; give them (and the exchange buffers) the semiring's neutral message
@@ -636,10 +613,8 @@ int gt_program_scatter_gather(gt_program *p) {
             break;
         }
         default:
-            if (p->Cx) k_msg_min_cx<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->Cx, p->s0,
-                                                                  g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
-            else k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->C, p->s0,
-                                                        g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
+            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->C, p->s0,
+                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
             break;
     }
     if (p->xseg && g->send_elems) {
@@ -836,12 +811,10 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             break;
         }
         case GT_BFS:
-            if (p->Cx) GT_HIP(hipMemsetAsync(p->Cx, 0, g->x_len, s));   // only the rows this apply changes are active next
-            if (nr) k_apply_bfs<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, p->Cx, g->R2X);
+            if (nr) k_apply_bfs<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
             break;
         default:
-            if (p->Cx) GT_HIP(hipMemsetAsync(p->Cx, 0, g->x_len, s));
-            if (nr) k_apply_min<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C, d_active, p->Cx, g->R2X);
+            if (nr) k_apply_min<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C, d_active);
             break;
     }
     GT_HIP(hipGetLastError());

@@ -106,7 +106,6 @@ struct gt_program {
     bool stationary = true;
     bool initialized = false;
     bool converged = false;
-    uint8_t *Cx = nullptr;       // min programs under the hubs-first layout: the changed flags C in SLOT order (engine.hip, k_msg_min_cx)
     bool check_sticky = false;   // vp:412-413: check_for_convergence is set by execute(0) and never cleared
     uint32_t iteration = 0;
     int semiring = 0;
