@@ -232,3 +232,74 @@ def test_config5_standin_cc_on_symmetrised_powerlaw_graph(gt):
     assert (comp_min[lab[:nv + 1]] == lab[:nv + 1]).all()
     print("config 5 stand-in: CC on symmetrised R-MAT-%d ef %d: %d iterations, %d components, checksum %s"
           % (scale, ef, its[0], int((lab[:nv + 1] == ids).sum()), cs))
+
+
+def _record_slices(gt, d, m, stride, step=1 << 26):
+    """The device-resident record stream in host slices of `step` records (u32 [n, stride])."""
+    L = gt._lib.lib()
+    for first in range(0, m, step):
+        cnt = min(step, m - first)
+        h = np.empty((cnt, stride), np.uint32)
+        gt._lib.check(L.gt_memcpy_d2h(h.ctypes.data_as(C.c_void_p), C.c_void_p(d.value + first * 4 * stride), cnt * 4 * stride))
+        yield h
+
+
+def test_config3_bfs_rmat26_properties_at_full_size(gt):
+    """BASELINE.json configs[2]: BFS on R-MAT-26 (2^30 records, symmetrised: 2.1 G stored entries), root = vertex 0 -- on one
+    GPU here; the 8-GPU form of the same code is covered at small sizes by tests/test_dist_native.py. Properties that pin
+    the result at any size, checked against the record stream itself: hops differ by at most one along every edge and
+    reachability is the same at both ends; every reached vertex but the root has a parent one level up that IS a neighbour,
+    and no neighbour one level up has a smaller id (the reference's min-combiner, bfs.h:61-63); iterations = depth + 1."""
+    scale, nv, root = 26, 1 << 26, 0
+    d, m = _device_rmat(gt, scale, 1)
+    G = gt.Graph(); G.load_device(d.value, m, nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = root; P.execute()
+    V = P.V; its = P.iteration; cs = P.checksum(out=None); nnz = int(G.info.nnz_local)
+    P.free(); G.free()
+    INF = gt.INF
+    hops, parent = V["hops"].astype(np.int64), V["parent"].astype(np.int64)
+    reached = hops != INF
+    assert hops[root] == 0 and parent[root] == root
+    has_parent_edge = np.zeros(hops.size, bool)
+    for h in _record_slices(gt, d, m, 2):
+        a, b = h[:, 0].astype(np.int64), h[:, 1].astype(np.int64)
+        keep = a != b; a, b = a[keep], b[keep]                     # self loops are dropped (bfs.cpp:26-30)
+        assert (reached[a] == reached[b]).all()
+        ra = reached[a]
+        ha, hb = hops[a][ra], hops[b][ra]; a, b = a[ra], b[ra]
+        assert (np.abs(ha - hb) <= 1).all()
+        for u, v, hu, hv in ((a, b, ha, hb), (b, a, hb, ha)):      # symmetrised: both directions are edges
+            up = hu + 1 == hv
+            assert not (u[up] < parent[v[up]]).any()               # no neighbour one level up with a smaller id
+            has_parent_edge[v[up][u[up] == parent[v[up]]]] = True
+    gt._lib.check(gt._lib.lib().gt_free(d))
+    chk = reached.copy(); chk[root] = False
+    assert has_parent_edge[chk].all() and (hops[parent[chk]] + 1 == hops[chk]).all()
+    assert its == int(hops[reached].max()) + 1                     # iteration t settles level t + 1; the last one finds nothing new
+    print("config 3: BFS R-MAT-26: %d stored entries, %d iterations, %d reached, checksum %s" % (nnz, its, int(reached.sum()), cs))
+
+
+def test_config4_sssp_rmat24_properties_at_full_size(gt):
+    """BASELINE.json configs[3]: SSSP on the weighted R-MAT-24 (2^28 records, weights 1..128, flags of apps/sssp.cpp), root 0,
+    on one GPU. Distances are THE shortest ones iff no record is violated (d[dst] <= d[src] + w) and every reached vertex
+    but the root has a tight incoming record (weights are positive, so the chain of tight records ends at the root)."""
+    scale, nv, root = 24, 1 << 24, 0
+    d, m = _device_rmat(gt, scale, 1, weighted=True)
+    G = gt.Graph(weighted=True); G.load_device(d.value, m, nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.SSSP_Program(G, False, True, False, gt._ROW_); P.root = root; P.execute()
+    dist = P.V["distance"].astype(np.int64); its = P.iteration; cs = P.checksum(out=None)
+    P.free(); G.free()
+    INF = gt.INF
+    assert dist[root] == 0
+    tight = np.zeros(dist.size, bool)
+    for h in _record_slices(gt, d, m, 3):
+        src, dst, w = h[:, 0].astype(np.int64), h[:, 1].astype(np.int64), h[:, 2].astype(np.int64)
+        ok = (src != dst) & (dist[src] != INF)                     # self loops are dropped (sssp.cpp:27-38)
+        src, dst, w = src[ok], dst[ok], w[ok]
+        via = dist[src] + w
+        assert (dist[dst] <= via).all()
+        tight[dst[dist[dst] == via]] = True
+    gt._lib.check(gt._lib.lib().gt_free(d))
+    reach = dist != INF; reach[root] = False
+    assert tight[reach].all()
+    print("config 4: SSSP R-MAT-24: %d iterations, %d reached, checksum %s" % (its, int(reach.sum()) + 1, cs))
