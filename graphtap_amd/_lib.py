@@ -58,7 +58,7 @@ class ExecStats(C.Structure):
                 ("scatter_gather_ms", C.c_double), ("combine_ms", C.c_double), ("apply_ms", C.c_double),
                 ("spmspv_iterations", C.c_uint32), ("phase_samples", C.c_uint32),
                 ("scatter_gather_sq", C.c_double), ("combine_sq", C.c_double), ("apply_sq", C.c_double),
-                ("cf_filtered_iterations", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("cf_filtered_iterations", C.c_uint32), ("list_iterations", C.c_uint32)]
 
 
 # every symbol include/graphtap_amd.h declares: (restype, argtypes)

@@ -485,7 +485,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double ms = 0; uint32_t n = 0;
         (void)gt_program_timing(p, &ms, &n, 1);
-        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered;
+        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = 0;
     }
     return GT_OK;
 }

@@ -164,29 +164,102 @@ __global__ void k_pr_cf_tail_c(const uint32_t *__restrict__ R2C, uint32_t nr, do
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x)
         if (R2C[r] == 0xFFFFFFFFu) rank_c[r] = alpha + (1.0 - alpha) * 0.0;
 }
-__global__ void k_apply_bfs(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
-                            uint32_t *__restrict__ parent, uint32_t *__restrict__ hops, uint8_t *__restrict__ C,
-                            uint32_t iteration, unsigned long long *d_active) {
+// All threads of a workgroup call (kernels.hip has the same helper for its lists): one reservation per workgroup.
+__device__ __forceinline__ void block_append(bool want, uint32_t value, uint32_t *__restrict__ list, unsigned int *__restrict__ cursor, uint32_t cap) {
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned round_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t b = __ballot(want);
+    if (lane == 0) wave_n[wave] = (unsigned)__popcll((unsigned long long)b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+        round_base = total ? atomicAdd(cursor, total) : 0u;
+    }
+    __syncthreads();
+    if (want) {
+        const uint32_t o = round_base + wave_n[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        if (o < cap) list[o] = value;
+    }
+    __syncthreads();
+}
+// applicator of one row: bfs.h:65-77 / sssp.h:57-65 (HAS_WEIGHT), cc.h:51-55; returns "changed"
+template <bool BFS>
+__device__ __forceinline__ bool apply_row(uint32_t v, uint32_t yv, uint32_t *__restrict__ s0, uint32_t *__restrict__ s1, uint32_t iteration) {
+    if constexpr (BFS) {
+        if (s1[v] == GT_INF && yv != GT_INF) { s1[v] = iteration + 1; s0[v] = yv; return true; }   // s1 = hops, s0 = parent
+        return false;
+    } else {
+        const uint32_t tmp = s0[v], nv = yv < tmp ? yv : tmp;
+        s0[v] = nv;
+        return nv != tmp;
+    }
+}
+// every row
+template <bool BFS>
+__global__ void __launch_bounds__(TPB) k_apply_rows(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
+                                                    uint32_t *__restrict__ s0, uint32_t *__restrict__ s1, uint8_t *__restrict__ C, uint32_t iteration,
+                                                    unsigned long long *d_active) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
-        uint32_t v = IR[r], yv = y[r];
-        uint8_t c = 0;  // bfs.h:65-77
-        if (hops[v] == GT_INF && yv != GT_INF) { hops[v] = iteration + 1; parent[v] = yv; c = 1; }
+        const uint32_t v = IR[r];
+        const bool c = apply_row<BFS>(v, y[r], s0, s1, iteration);
         C[v] = c; act += c;
     }
     count_active(act, d_active);
 }
-__global__ void k_apply_min(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
-                            uint32_t *__restrict__ s0, uint8_t *__restrict__ C, unsigned long long *d_active) {
+// the list of the vertices a full apply changed, from their flags -- run only when the count it returned fits a list (appending
+// inside the full apply costs two barriers and a reservation per 256 rows: 1.5 instead of 0.3 ms when millions change). A
+// workgroup reserves once per 4096 rows: reservations all hit one word, and 10^5 of them are a millisecond.
+__global__ void __launch_bounds__(TPB) k_list_from_flags(const uint32_t *__restrict__ IR, uint32_t nr, const uint8_t *__restrict__ C,
+                                                         uint32_t *__restrict__ next, unsigned int *__restrict__ next_n, uint32_t cap) {
+    constexpr uint32_t PER = 16, SPAN = PER * TPB;
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned span_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nspan = (nr + SPAN - 1) / SPAN;
+    for (uint32_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+        uint32_t mask = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t r = sp * SPAN + k * TPB + threadIdx.x;
+            if (r < nr && C[IR[r]]) { mask |= 1u << k; cnt++; }
+        }
+        uint32_t inc = cnt;   // inclusive prefix over the wave
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        if (lane == 63) wave_n[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+            span_base = total ? atomicAdd(next_n, total) : 0u;
+        }
+        __syncthreads();
+        uint32_t o = span_base + wave_n[wave] + inc - cnt;
+        for (uint32_t k = 0; mask; k++, mask >>= 1)
+            if (mask & 1u) { if (o < cap) next[o] = IR[sp * SPAN + k * TPB + threadIdx.x]; o++; }
+        __syncthreads();
+    }
+}
+// only the rows the SpMSpV lowered (fl_rows); C of the vertices that were active is cleared by k_list_clear_flags first
+template <bool BFS>
+__global__ void __launch_bounds__(TPB) k_apply_list(const uint32_t *__restrict__ rows, const unsigned int *__restrict__ n_dev, const uint32_t *__restrict__ y,
+                                                    const uint32_t *__restrict__ IR, uint32_t *__restrict__ s0, uint32_t *__restrict__ s1,
+                                                    uint8_t *__restrict__ C, uint32_t iteration, unsigned long long *d_active,
+                                                    uint32_t *__restrict__ next, unsigned int *__restrict__ next_n, uint32_t cap) {
     unsigned act = 0;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
-        uint32_t v = IR[r], yv = y[r], tmp = s0[v];  // sssp.h:57-65 (HAS_WEIGHT), cc.h:51-55
-        uint32_t nv = yv < tmp ? yv : tmp;
-        s0[v] = nv;
-        uint8_t c = (nv != tmp);
-        C[v] = c; act += c;
+    const uint32_t n = *n_dev, n_round = (n + TPB - 1) / TPB * TPB;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_round; t += gridDim.x * blockDim.x) {
+        bool c = false; uint32_t v = 0;
+        if (t < n) { const uint32_t r = rows[t]; v = IR[r]; c = apply_row<BFS>(v, y[r], s0, s1, iteration); C[v] = c; act += c; }
+        block_append(c, v, next, next_n, cap);
     }
     count_active(act, d_active);
+}
+__global__ void k_list_clear_flags(uint8_t *__restrict__ C, const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_dev) {
+    const uint32_t n = *n_dev;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) C[list[i]] = 0;
 }
 // the TCSC_CF converged tail (vp:425-428 -> 1683-1691): source rows get alpha + (1-alpha) * 0 (k_pr_cf_tail_c above)
 
@@ -417,7 +490,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+    void *ptrs[] = {p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -457,6 +530,16 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
+    {   // frontier lists: min programs on one rank (the multi-rank drivers run the sliced combine, which has no sparse path)
+        const char *fe = getenv("GRAPHTAP_FRONTIER_LISTS");
+        p->fl_enabled = !p->stationary && !gt_has_exchange(g) && g->info.nranks == 1 && !(fe && atoi(fe) == 0);
+        if (ok && p->fl_enabled) {
+            p->fl_rows_cap = std::max<uint32_t>(g->info.nnzrows, 1);
+            ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess &&
+                 hipMalloc((void **)&p->fl_rows, (uint64_t)p->fl_rows_cap * 4) == hipSuccess &&
+                 hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess;
+        }
+    }
     if (ok && prm->kind == GT_PR) {
         const uint64_t nr = std::max<uint32_t>(g->info.nnzrows, 1);
         ok = hipMalloc((void **)&p->rank, (uint64_t)H * 8) == hipSuccess && hipMalloc((void **)&p->rank_c, nr * 8) == hipSuccess &&
@@ -514,6 +597,19 @@ static int init_common(gt_program *p) {
             break;
         default:
             k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
+            if (p->fl_enabled) {   // the first frontier: the root alone (bfs.h:37-50, sssp.h:33-42), every vertex for CC (cc.h:33-36: no list)
+                GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)g->info.nnzrows / 32 + 1) * 4, s));
+                GT_HIP(hipMemsetAsync(p->d_fl, 0, 4 * sizeof(unsigned int), s));
+                p->fl_cur = 0; p->fl_prev_valid = true; p->fl_prev_n = 0; p->fl_rows_valid = false; p->list_iters = 0;
+                p->fl_cur_valid = p->prm.kind != GT_CC; p->fl_cur_n = 0;
+                if (p->fl_cur_valid && p->prm.root < H) {   // one rank: slot index = vertex id
+                    const unsigned int one = 1;
+                    GT_HIP(hipMemcpyAsync(p->fl_v[0], &p->prm.root, 4, hipMemcpyHostToDevice, s));
+                    GT_HIP(hipMemcpyAsync(p->d_fl, &one, sizeof(one), hipMemcpyHostToDevice, s));
+                    GT_HIP(hipStreamSynchronize(s));   // `one` is on this stack frame
+                    p->fl_cur_n = 1;
+                }
+            }
             break;
     }
     // messages: padding columns are never referenced; give them (and the exchange buffers) the semiring's neutral message
@@ -613,8 +709,11 @@ int gt_program_scatter_gather(gt_program *p) {
             break;
         }
         default:
-            k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->C, p->s0,
-                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
+            if (p->fl_enabled && p->fl_cur_valid && p->fl_prev_valid) {   // both frontiers are lists: x changes in their slots only
+                int st = gt_frontier_messages(p, s); if (st != GT_OK) return st;
+            } else
+                k_msg_min<<<grid_for(nc), TPB, 0, s>>>((uint32_t *)xm, xv, nc, p->C, p->s0,
+                                                       g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
             break;
     }
     if (p->xseg && g->send_elems) {
@@ -670,6 +769,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         const bool fuse = hi >= K && fused_epilogue(p, &epi);
         if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
         bool sparse_done = false;
+        p->fl_rows_valid = false;
         if (!p->stationary && lo == 0 && hi >= K) { int st = gt_spmspv_try(p, s, &sparse_done); if (st != GT_OK) return st; }
         // TCSC_CF computation filtering (compressed_column.hpp:671-708, vp:1264-1317): the entries of source rows matter on
         // the last iteration only (never in converge mode, SURVEY trap 5); their chunks stay out until then
@@ -786,6 +886,7 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
                "apply() after a fused combine must use the arguments the fusion was armed with");
     if (d_active && !fused) GT_HIP(hipMemsetAsync(d_active, 0, sizeof(unsigned long long), s));
     const bool cf = (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF);
+    bool list_from_flags = false;
     if (p->iteration == 0 && !cf) k_clear_empty_rows<<<grid_for(H), TPB, 0, s>>>(p->C, g->IJ, H);
     switch (p->prm.kind) {
         case GT_DEG:
@@ -810,12 +911,31 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
             break;
         }
-        case GT_BFS:
-            if (nr) k_apply_bfs<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
+        default: {   // BFS, SSSP, CC
+            const bool bfs = p->prm.kind == GT_BFS;
+            const bool lists = p->fl_enabled && active != nullptr;   // the host learns the length of the next list from the active count
+            uint32_t *next = lists ? p->fl_v[p->fl_cur ^ 1] : nullptr;
+            unsigned int *next_n = lists ? p->d_fl + (p->fl_cur ^ 1) : nullptr;
+            if (lists) GT_HIP(hipMemsetAsync(next_n, 0, sizeof(unsigned int), s));
+            if (lists && p->fl_rows_valid && p->fl_cur_valid) {
+                // the SpMSpV of this iteration left the rows it lowered: no other row can change; the vertices that were active
+                // (the current list) are the only ones whose flag is set
+                const unsigned gl = (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)p->fl_cur_n + TPB - 1) / TPB, 4096), 1);
+                if (p->fl_cur_n) k_list_clear_flags<<<gl, TPB, 0, s>>>(p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur);
+                const unsigned ga = 1024;   // the length is on the device; the rounds are uniform per workgroup
+                if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
+                else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
+                GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)nr / 32 + 1) * 4, s));
+                p->list_iters++;
+            } else {
+                if (nr && bfs) k_apply_rows<true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
+                else if (nr) k_apply_rows<false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
+                if (p->fl_enabled && p->fl_rows_valid) GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)nr / 32 + 1) * 4, s));
+                list_from_flags = lists;   // once the count is known (below)
+            }
+            p->fl_rows_valid = false;
             break;
-        default:
-            if (nr) k_apply_min<<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->C, d_active);
-            break;
+        }
     }
     GT_HIP(hipGetLastError());
     p->iteration++;  // vp:421
@@ -826,6 +946,15 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         *active = h;
         p->last_active = h;
     } else p->last_active = ~0ull;
+    if (p->fl_enabled && !p->stationary) {   // the list of the vertices this apply changed becomes the current frontier
+        p->fl_prev_valid = p->fl_cur_valid; p->fl_prev_n = p->fl_cur_n;
+        p->fl_cur ^= 1;
+        p->fl_cur_valid = active != nullptr && p->last_active <= GT_FRONTIER_CAP;
+        p->fl_cur_n = p->fl_cur_valid ? (uint32_t)p->last_active : 0;
+        if (p->fl_cur_valid && list_from_flags && nr && p->fl_cur_n)   // a full apply that changed few: collect them
+            k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur, GT_FRONTIER_CAP);
+        GT_HIP(hipGetLastError());
+    }
     return GT_OK;
 }
 
@@ -848,7 +977,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0;
     GT_HIP(hipStreamSynchronize(s));
     auto t0 = std::chrono::steady_clock::now();
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
@@ -888,7 +1017,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
         stats->scatter_gather_sq = q_sg; stats->combine_sq = q_cb; stats->apply_sq = q_ap; stats->phase_samples = samples;
         stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
-        stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered;
+        stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = p->list_iters;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

@@ -147,6 +147,19 @@ struct gt_program {
     unsigned long long *d_frontier = nullptr;                           // [2] active columns, entries in them
     uint64_t last_active = ~0ull;                                       // vertices the previous apply() activated (converge mode), or ~0 if unknown
     uint32_t spmspv_iters = 0;                                          // iterations of the current execute() that took the sparse path
+    // FRONTIER LISTS (min programs on one rank, converge mode): every apply() appends the vertices it changes to a list; while that
+    // list is short (<= GT_FRONTIER_CAP) the next iteration never walks a full vector -- the messenger resets the previous
+    // frontier's slots of x and writes the new ones, the SpMSpV takes its columns from the list and emits the rows it lowers
+    // (de-duplicated through row_mark), and apply() visits those rows only (engine.hip, kernels.hip).
+    uint32_t *fl_v[2] = {nullptr, nullptr};   // [GT_FRONTIER_CAP] vertex lists: fl_v[fl_cur] = vertices changed by the last apply
+    uint32_t *fl_rows = nullptr;              // [fl_rows_cap] rows the SpMSpV of this iteration lowered
+    uint8_t *row_mark = nullptr;              // [nnzrows] 1 = already in fl_rows (zero between iterations)
+    unsigned int *d_fl = nullptr;             // [4] device counters: elements of fl_v[0], fl_v[1], fl_rows
+    uint32_t fl_rows_cap = 0;
+    int fl_cur = 0;
+    bool fl_enabled = false, fl_cur_valid = false, fl_prev_valid = false, fl_rows_valid = false;
+    uint32_t fl_cur_n = 0, fl_prev_n = 0;     // host copies of the two list lengths (valid lists only)
+    uint32_t list_iters = 0;                  // iterations of the current execute() whose three phases all ran on lists
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
     bool cf_hint = false;
@@ -158,6 +171,7 @@ struct gt_program {
     std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
 };
 
+#define GT_FRONTIER_CAP (1u << 20)   // longest frontier kept as a list
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
 #ifndef GT_PB_WINDOW
 #define GT_PB_WINDOW 16383u   // columns per DENSE phase-1 window (pb.hip): LDS slot GT_PB_WINDOW holds the neutral message that pad
@@ -217,6 +231,8 @@ inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv
 // over the entries of the ACTIVE columns only. Counts first; runs only if they hold at most nnz / 1024 entries (or GRAPHTAP_SPMSPV
 // forces it); *done tells whether the SpMV is complete.
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
+// the messenger over the frontier lists: resets the slots of the previous frontier, writes the messages of the current one
+int gt_frontier_messages(gt_program *p, hipStream_t s);
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the

@@ -156,19 +156,94 @@ __global__ void __launch_bounds__(TPB) k_frontier_list(const uint32_t *__restric
         __syncthreads();   // wave_n / round_base are rewritten by the next round
     }
 }
-// one thread per entry of an active column: the column is found by bisection of the entry offsets
-template <bool WEIGHTED>
-__global__ void k_spmspv_min(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ off, uint32_t nact,
-                             uint64_t total, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
-                             uint32_t *__restrict__ y) {
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t lo = 0, hi = nact;   // last i with off[i] <= t
-        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
-        const uint32_t e = JA[col[lo]] + (uint32_t)(t - off[lo]);
-        const uint32_t r = IA[e];
-        const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
-        if (m < y[r]) atomicMin(&y[r], m);
+// All threads of a workgroup call: the ones with `want` get consecutive positions of `list` (one atomic per workgroup: every
+// reservation hits the same word). Positions at or beyond `cap` are counted but not written -- the host sees the overflow.
+__device__ __forceinline__ void block_append(bool want, uint32_t value, uint32_t *__restrict__ list, unsigned int *__restrict__ cursor, uint32_t cap) {
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned round_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t b = __ballot(want);
+    if (lane == 0) wave_n[wave] = (unsigned)__popcll((unsigned long long)b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+        round_base = total ? atomicAdd(cursor, total) : 0u;
     }
+    __syncthreads();
+    if (want) {
+        const uint32_t o = round_base + wave_n[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+        if (o < cap) list[o] = value;
+    }
+    __syncthreads();   // wave_n / round_base are rewritten by the next call
+}
+
+// one thread per entry of an active column: the column is found by bisection of the entry offsets. EMIT: the rows whose
+// accumulator this pass lowers -- the only rows apply() can change -- go to `rows_out`, once each (mark bits).
+template <bool WEIGHTED, bool EMIT>
+__global__ void __launch_bounds__(TPB) k_spmspv_min(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ off, uint32_t nact,
+                             uint64_t total, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
+                             uint32_t *__restrict__ y, uint32_t *__restrict__ mark_bits, uint32_t *__restrict__ rows_out, unsigned int *__restrict__ rows_n,
+                             uint32_t rows_cap) {
+    const uint64_t n_round = EMIT ? (total + TPB - 1) / TPB * TPB : total;   // block_append needs every thread in every round
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * blockDim.x) {
+        bool emit = false;
+        uint32_t r = 0;
+        if (t < total) {
+            uint32_t lo = 0, hi = nact;   // last i with off[i] <= t
+            while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
+            const uint32_t e = JA[col[lo]] + (uint32_t)(t - off[lo]);
+            r = IA[e];
+            const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
+            if (m < y[r]) {
+                const uint32_t old = atomicMin(&y[r], m);
+                if (EMIT && m < old) { const uint32_t bit = 1u << (r & 31u); emit = !(atomicOr(&mark_bits[r >> 5], bit) & bit); }
+            }
+        }
+        if constexpr (EMIT) block_append(emit, r, rows_out, rows_n, rows_cap);
+    }
+}
+
+// ---- frontier lists (vertices changed by the last apply)
+__device__ __forceinline__ uint32_t slot_of_vertex(const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ xslot, uint32_t v) {
+    if (!(IJ[v] & 2u)) return 0xFFFFFFFFu;   // no column: the vertex sends nothing
+    const uint32_t c = JV[v];
+    return xslot ? xslot[c] : c;
+}
+__global__ void k_list_reset_x(uint32_t *__restrict__ x, const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_dev,
+                               const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ xslot) {
+    const uint32_t n = *n_dev;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t sl = slot_of_vertex(IJ, JV, xslot, list[i]);
+        if (sl != 0xFFFFFFFFu) x[sl] = GT_INF;
+    }
+}
+__global__ void k_list_msg(uint32_t *__restrict__ x, const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_dev,
+                           const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ xslot,
+                           const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind) {
+    const uint32_t n = *n_dev;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = list[i], sl = slot_of_vertex(IJ, JV, xslot, v);
+        if (sl != 0xFFFFFFFFu) x[sl] = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+    }
+}
+// the frontier's columns, messages and entry counts straight from the list (a vertex without a column counts zero entries)
+__global__ void k_list_frontier(const uint32_t *__restrict__ list, uint32_t n, const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV,
+                                const uint32_t *__restrict__ JA, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind,
+                                uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg, unsigned long long *__restrict__ out) {
+    unsigned long long e = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = list[i];
+        uint32_t c = 0, d = 0;
+        if (IJ[v] & 2u) { c = JV[v]; d = JA[c + 1] - JA[c]; }
+        col[i] = c; deg[i] = d; val[i] = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];
+        e += d;
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    __shared__ unsigned long long part[TPB / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; w++) e += part[w]; if (e) atomicAdd(&out[1], e); }
 }
 
 }  // namespace
@@ -190,6 +265,8 @@ int gt_spmspv_reserve(gt_program *p, uint32_t nact) {
     return GT_OK;
 }
 
+static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done);
+
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     *done = false;
     const gt_graph *g = p->g;
@@ -199,6 +276,8 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     const uint64_t nnz = g->info.nnz_local;
     if (nnz == 0) return GT_OK;
     const bool force = env && atoi(env) == 1;
+    p->fl_rows_valid = false;
+    if (p->fl_enabled && p->fl_cur_valid) return spmspv_from_list(p, s, force, done);
     // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
     // count the converge-mode driver reads anyway) activated few vertices
     static const uint64_t max_active = getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE")) : 16384;
@@ -234,11 +313,60 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     }
     const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
     if (p->semiring == GT_MINPLUS_U32)
-        k_spmspv_min<true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y);
+        k_spmspv_min<true, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y, nullptr, nullptr, nullptr, 0);
     else
-        k_spmspv_min<false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y);
+        k_spmspv_min<false, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y, nullptr, nullptr, nullptr, 0);
     GT_HIP(hipGetLastError());
     p->spmspv_iters++;
     *done = true;
+    return GT_OK;
+}
+
+// The same from the frontier LIST (gt_internal.h): no pass over x; the rows it lowers are left in fl_rows for apply().
+static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done) {
+    const gt_graph *g = p->g;
+    const uint32_t nact = p->fl_cur_n;
+    if (nact == 0) { *done = true; p->fl_rows_valid = true; GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s)); return GT_OK; }   // nothing is active: y keeps its minima
+    if (p->fr_cap < nact + 1) { int st = gt_spmspv_reserve(p, nact); if (st != GT_OK) return st; }
+    GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
+    const unsigned grid = (unsigned)std::min<uint64_t>((nact + TPB - 1) / TPB, 4096);
+    k_list_frontier<<<grid, TPB, 0, s>>>(p->fl_v[p->fl_cur], nact, g->IJ, g->JV, g->JA, p->s0, g->info.rank * g->info.tile_height, gt_vidmap_of(g),
+                                         p->prm.kind, p->fr_col, p->fr_val, p->fr_off, p->d_frontier);
+    unsigned long long h[2] = {0, 0};
+    GT_HIP(hipMemcpyAsync(h, p->d_frontier, sizeof(h), hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
+    if (h[1] == 0) { *done = true; p->fl_rows_valid = true; return GT_OK; }
+    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 1024;
+    if (!force && h[1] > g->info.nnz_local / frac) return GT_OK;   // the streaming pass does it (x is complete either way)
+    GT_REQUIRE(h[1] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "frontier entry offsets exceed 32 bits");
+    {
+        size_t tb = 0;
+        GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, nact, s));
+        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+        GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
+    }
+    const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
+    if (p->semiring == GT_MINPLUS_U32)
+        k_spmspv_min<true, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y,
+                                                    (uint32_t *)p->row_mark, p->fl_rows, p->d_fl + 2, p->fl_rows_cap);
+    else
+        k_spmspv_min<false, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y,
+                                                     (uint32_t *)p->row_mark, p->fl_rows, p->d_fl + 2, p->fl_rows_cap);
+    GT_HIP(hipGetLastError());
+    p->spmspv_iters++;
+    p->fl_rows_valid = true;
+    *done = true;
+    return GT_OK;
+}
+
+int gt_frontier_messages(gt_program *p, hipStream_t s) {
+    const gt_graph *g = p->g;
+    const unsigned int *n_prev = p->d_fl + (p->fl_cur ^ 1), *n_cur = p->d_fl + p->fl_cur;
+    auto grid = [](uint32_t n) { return (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)n + TPB - 1) / TPB, 4096), 1); };
+    if (p->fl_prev_n) k_list_reset_x<<<grid(p->fl_prev_n), TPB, 0, s>>>((uint32_t *)p->x, p->fl_v[p->fl_cur ^ 1], n_prev, g->IJ, g->JV, g->xslot);
+    if (p->fl_cur_n) k_list_msg<<<grid(p->fl_cur_n), TPB, 0, s>>>((uint32_t *)p->x, p->fl_v[p->fl_cur], n_cur, g->IJ, g->JV, g->xslot, p->s0,
+                                                                   g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
+    GT_HIP(hipGetLastError());
     return GT_OK;
 }

@@ -175,7 +175,8 @@ typedef struct gt_exec_stats {
     double scatter_gather_sq, combine_sq, apply_sq;
     uint32_t cf_filtered_iterations; /* PageRank under GT_TCSC_CF: SpMVs that left the entries of source rows out (computation
                                         filtering, compressed_column.hpp:671-708, vp:1264-1317: all but the last iteration) */
-    uint32_t reserved_;
+    uint32_t list_iterations;        /* BFS / SSSP / CC on one rank: iterations whose three phases all ran on frontier lists (messenger over
+                                        the changed vertices, SpMSpV over their columns, apply over the rows it lowered) */
 } gt_exec_stats;
 
 /* state fields for gt_program_copy_state */

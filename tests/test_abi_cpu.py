@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(tmp_path):
     from graphtap_amd import _lib
     pairs = [("gt_graph_flags", _lib.GraphFlags, "parallel_edges"), ("gt_graph_info", _lib.GraphInfo, "send_elems"),
              ("gt_tile_arrays", _lib.TileArrays, "L2G"), ("gt_exchange_plan", _lib.ExchangePlan, "recv_counts"),
-             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "reserved_")]
+             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "list_iterations")]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "graphtap_amd.h"\nint main(void){' +
                    "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, m) for c, _, m in pairs) + "return 0;}")

@@ -344,6 +344,44 @@ def test_sparse_frontier_spmspv_is_bit_exact(gt, name, mode, known_answers, monk
     assert (r["stats"].spmspv_iterations > 0) == (mode == "1")
 
 
+@pytest.mark.parametrize("lists", ["1", "0"])
+@pytest.mark.parametrize("spmspv", [None, "1"])
+def test_frontier_lists_are_bit_exact(gt, O, lists, spmspv, known_answers, monkeypatch):
+    """Frontier lists (one rank, converge mode): while the last apply changed few vertices, the messenger touches only the
+    slots of the previous and the new frontier, the SpMSpV takes its columns from the list and emits the rows it lowers, and
+    apply visits those rows only. Labels, parents AND iteration counts must be the reference's with the lists on and off, with
+    the sparse path by size and forced; mid-size R-MAT against the oracle, where big and small frontiers alternate."""
+    from graphtap_amd.rmat import rmat_edges
+    monkeypatch.setenv("GRAPHTAP_FRONTIER_LISTS", lists)
+    if spmspv: monkeypatch.setenv("GRAPHTAP_SPMSPV", spmspv)
+
+    def check_lists(r):   # by size, a graph this small never takes the sparse path (nnz / 1024 entries): only the forced mode must
+        if lists == "0": assert r["stats"].list_iterations == 0
+        elif spmspv == "1": assert r["stats"].list_iterations > 0
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
+        for root, tag in ((c["root"], ""), (0, "0")) if c["root"] != 0 else ((0, ""),):
+            r = run_min(gt, "bfs", c["edges"], nv, root)
+            assert (r["parent"][:n] == c["np1_bfs%s_a" % tag]).all() and (r["hops"][:n] == c["np1_bfs%s_b" % tag]).all()
+            assert r["iterations"] == k["np1_bfs" + tag]["iterations"]
+            check_lists(r)
+            r = run_min(gt, "sssp", c["wedges"], nv, root)
+            assert (r["distance"][:n] == c["np1_sssp%s_a" % tag]).all() and r["iterations"] == k["np1_sssp" + tag]["iterations"]
+            check_lists(r)
+        r = run_min(gt, "cc", c["edges"], nv)
+        assert (r["label"][:n] == c["np1_cc_a"]).all() and r["iterations"] == k["np1_cc"]["iterations"]
+        if lists == "0": assert r["stats"].list_iterations == 0
+    w = rmat_edges(17, 16, 5, weighted=True); e = np.ascontiguousarray(w[:, :2]); nv = 1 << 17
+    for root in (0, 77):
+        want = O.run_app("bfs", e, nv, root=root); got = run_min(gt, "bfs", e, nv, root)
+        assert (got["parent"] == want["parent"]).all() and (got["hops"] == want["hops"]).all() and got["iterations"] == want["iterations"]
+        want = O.run_app("sssp", w, nv, root=root); got = run_min(gt, "sssp", w, nv, root)
+        assert (got["distance"] == want["distance"]).all() and got["iterations"] == want["iterations"]
+    want = O.run_app("cc", e, nv); got = run_min(gt, "cc", e, nv)
+    assert (got["label"] == want["label"]).all() and got["iterations"] == want["iterations"]
+    if lists == "1": assert got["stats"].list_iterations > 0   # the tail iterations of CC
+
+
 def test_display_lines_match_survey_table(gt):
     """First states printed by the reference on its bundled sample."""
     c = load_case("rmat10")
