@@ -86,7 +86,7 @@ for app in args.apps.split(","):
     if app != "deg":
         req, per_it = required_bytes(L, G, P, app)
         assert len(per_it) == st.iterations, (len(per_it), st.iterations)
-        extra = {"required_bytes": req, "required_GBps": req / st.seconds / 1e9, "required_frac": req / st.seconds / 8e12, "per_iteration": per_it}
+        extra = {"required_bytes": req, "required_GBps": req / st.seconds / 1e9, "required_frac": req / st.seconds / 8e12, "required_frac_warm": req / warm / 8e12, "per_iteration": per_it}
     print(json.dumps({"app": app, "scale": scale, "edge_factor": args.edge_factor, "root": int(P.root), "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
                       "iterations": st.iterations, "sparse_iterations": int(st.spmspv_iterations), "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
                       "execute_warm_s": warm, "GTEPS_warm": G.info.nnz_local * st.iterations / warm / 1e9, "list_iterations": int(st.list_iterations),
