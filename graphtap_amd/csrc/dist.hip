@@ -70,6 +70,7 @@ Rccl *rccl() {
         if (r_ != ncclSuccess) { gt_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, rccl()->GetErrorString(r_)); return GT_ERR_HIP; } \
     } while (0)
 
+__global__ void k_dist_preload() {}
 __global__ void k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
 }
@@ -455,6 +456,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
     (void)gt_program_enable_timing(p, stats != nullptr);
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
+    k_dist_preload<<<1, 64, 0, s>>>();   // this file's code object is loaded at its first launch (milliseconds): not inside the timed loop
     GT_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {

@@ -626,6 +626,7 @@ static int init_common(gt_program *p) {
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
     if (!p->stationary && p->prm.order == GT_ROW) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
+    { int st = gt_kernels_preload(s); if (st != GT_OK) return st; }
     p->initialized = true;
     return pr_pack_state(p);
 }

@@ -233,6 +233,7 @@ inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
 // the messenger over the frontier lists: resets the slots of the previous frontier, writes the messages of the current one
 int gt_frontier_messages(gt_program *p, hipStream_t s);
+int gt_kernels_preload(hipStream_t s);   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
