@@ -128,7 +128,7 @@ struct NonZero {
 // pre-aggregate several times better (pb.hip) -- the hubs-first layout of the single-rank build, block by block, at no
 // cost at run time because the sender packs its buffer through an index list anyway (k_pack_send). `Pneed[col]` is that
 // position; the owner computes the same order from the same counts (k_send_list, Pby).
-struct BlockTab { uint32_t clo, sneed_lo, base; };   // first internal column id of block (k,s); Sneed there; first local id
+struct BlockTab { uint32_t base; };   // first local column id of block (k,s)
 
 __device__ __forceinline__ uint32_t local_col(const BlockTab *__restrict__ tab, const uint32_t *__restrict__ Scol,
                                               const uint32_t *__restrict__ Pneed, uint32_t H, uint32_t T, uint32_t p, uint32_t col) {
@@ -207,7 +207,7 @@ __global__ void k_local_to_global(const uint32_t *__restrict__ needme, uint64_t 
     }
 }
 // send list: element i of the send buffer is the message of owned compressed column send_idx[i]
-struct SendTab { uint32_t sby_lo, base; };   // Sby at the first column of block (k,d); first send-buffer element of the block
+struct SendTab { uint32_t base; };   // first send-buffer element of block (k,d)
 __global__ void k_send_list(const uint32_t *__restrict__ needby, const uint32_t *__restrict__ Pby, const uint32_t *__restrict__ Scol,
                             const SendTab *__restrict__ tab, uint32_t H, uint32_t T, uint32_t p, uint32_t col_lo, uint32_t *__restrict__ send_idx) {
     const uint64_t n = (uint64_t)p * H;
@@ -437,8 +437,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
                 const uint32_t nrecv = (sneed_at[(kk + 1) * p + q] - sneed_at[kk * p + q] + 3u) & ~3u;
                 const uint32_t nsend = (sby_at[(kk + 1) * p + q] - sby_at[kk * p + q] + 3u) & ~3u;
                 GT_REQUIRE(xo + nrecv < 0xFFFFFFF0ull && so + nsend < 0xFFFFFFF0ull, GT_ERR_UNSUPPORTED, "exchange buffers exceed 32-bit indexing");
-                rtab[kk * p + q] = BlockTab{clo[kk * p + q], sneed_at[kk * p + q], (uint32_t)xo};
-                stab[kk * p + q] = SendTab{sby_at[kk * p + q], (uint32_t)so};
+                rtab[kk * p + q] = BlockTab{(uint32_t)xo};
+                stab[kk * p + q] = SendTab{(uint32_t)so};
                 g->recv_counts[kk * p + q] = nrecv; g->send_counts[kk * p + q] = nsend;
                 xo += nrecv; so += nsend;
             }
