@@ -252,8 +252,11 @@ __global__ void __launch_bounds__(TPB) k_apply_list(const uint32_t *__restrict__
     const uint32_t n = *n_dev, n_round = (n + TPB - 1) / TPB * TPB;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_round; t += gridDim.x * blockDim.x) {
         bool c = false; uint32_t v = 0;
-        if (t < n) { const uint32_t r = rows[t]; v = IR[r]; c = apply_row<BFS>(v, y[r], s0, s1, iteration); C[v] = c; act += c; }
-        block_append(c, v, next, next_n, cap);
+        if (t < n) {
+            const uint32_t r = rows[t];
+            if (r != 0xFFFFFFFFu) { v = IR[r]; c = apply_row<BFS>(v, y[r], s0, s1, iteration); C[v] = c; act += c; }   // ~0u: a bottom-up row that found nobody
+        }
+        if (__syncthreads_or(c)) block_append(c, v, next, next_n, cap);
     }
     count_active(act, d_active);
 }
@@ -490,7 +493,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+    void *ptrs[] = {p->bu_rows, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -538,6 +541,8 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
             ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess &&
                  hipMalloc((void **)&p->fl_rows, (uint64_t)p->fl_rows_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess;
+            if (ok && prm->kind == GT_BFS && !g->flags.directed)   // symmetric graph: bottom-up steps are possible (kernels.hip)
+                ok = hipMalloc((void **)&p->bu_rows, (uint64_t)std::max<uint32_t>(g->info.nnzrows, 1) * 4) == hipSuccess;
         }
     }
     if (ok && prm->kind == GT_PR) {
@@ -601,6 +606,7 @@ static int init_common(gt_program *p) {
                 GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)g->info.nnzrows / 32 + 1) * 4, s));
                 GT_HIP(hipMemsetAsync(p->d_fl, 0, 4 * sizeof(unsigned int), s));
                 p->fl_cur = 0; p->fl_prev_valid = true; p->fl_prev_n = 0; p->fl_rows_valid = false; p->list_iters = 0;
+                p->bfs_settled = (p->prm.root < H) ? 1 : 0; p->bottom_up_iters = 0;
                 p->fl_cur_valid = p->prm.kind != GT_CC; p->fl_cur_n = 0;
                 if (p->fl_cur_valid && p->prm.root < H) {   // one rank: slot index = vertex id
                     const unsigned int one = 1;
@@ -918,11 +924,12 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             uint32_t *next = lists ? p->fl_v[p->fl_cur ^ 1] : nullptr;
             unsigned int *next_n = lists ? p->d_fl + (p->fl_cur ^ 1) : nullptr;
             if (lists) GT_HIP(hipMemsetAsync(next_n, 0, sizeof(unsigned int), s));
-            if (lists && p->fl_rows_valid && p->fl_cur_valid) {
-                // the SpMSpV of this iteration left the rows it lowered: no other row can change; the vertices that were active
-                // (the current list) are the only ones whose flag is set
+            if (lists && p->fl_rows_valid) {
+                // the SpMSpV (or the bottom-up step) of this iteration left the rows it lowered: no other row can change; the
+                // vertices that were active -- the current list, if there is one -- are the only ones whose flag is set
                 const unsigned gl = (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)p->fl_cur_n + TPB - 1) / TPB, 4096), 1);
-                if (p->fl_cur_n) k_list_clear_flags<<<gl, TPB, 0, s>>>(p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur);
+                if (!p->fl_cur_valid) GT_HIP(hipMemsetAsync(p->C, 0, H, s));
+                else if (p->fl_cur_n) k_list_clear_flags<<<gl, TPB, 0, s>>>(p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur);
                 const unsigned ga = 1024;   // the length is on the device; the rounds are uniform per workgroup
                 if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
                 else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
@@ -946,6 +953,7 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
         GT_HIP(hipStreamSynchronize(s));
         *active = h;
         p->last_active = h;
+        if (p->prm.kind == GT_BFS) p->bfs_settled += h;
     } else p->last_active = ~0ull;
     if (p->fl_enabled && !p->stationary) {   // the list of the vertices this apply changed becomes the current frontier
         p->fl_prev_valid = p->fl_cur_valid; p->fl_prev_n = p->fl_cur_n;

@@ -160,6 +160,11 @@ struct gt_program {
     bool fl_enabled = false, fl_cur_valid = false, fl_prev_valid = false, fl_rows_valid = false;
     uint32_t fl_cur_n = 0, fl_prev_n = 0;     // host copies of the two list lengths (valid lists only)
     uint32_t list_iters = 0;                  // iterations of the current execute() whose three phases all ran on lists
+    // BOTTOM-UP BFS steps (symmetric graphs): once fewer rows are unreached than vertices are active, the unreached rows look
+    // their parent up (minimum id among the neighbours on the current level -- the same value the push sweep leaves in y)
+    uint32_t *bu_rows = nullptr;              // [nnzrows] rows of unreached vertices
+    uint64_t bfs_settled = 0;                 // rows reached so far (host estimate from the active counts)
+    uint32_t bottom_up_iters = 0;
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
     bool cf_hint = false;

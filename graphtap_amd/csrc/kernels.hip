@@ -206,6 +206,74 @@ __global__ void __launch_bounds__(TPB) k_spmspv_min(const uint32_t *__restrict__
 
 __global__ void k_preload() {}
 
+// ---- bottom-up BFS step on a SYMMETRIC graph: the in-neighbours of row r are the entries of the same vertex's column
+// rows of the vertices BFS has not reached (+ the entries of their columns), one reservation per 4096 rows
+__global__ void __launch_bounds__(TPB) k_bu_collect(const uint32_t *__restrict__ IR, const uint32_t *__restrict__ R2C, const uint32_t *__restrict__ JA,
+                                                    const uint32_t *__restrict__ hops, uint32_t nr, uint32_t *__restrict__ list,
+                                                    unsigned int *__restrict__ list_n, unsigned long long *__restrict__ entries) {
+    constexpr uint32_t PER = 16, SPAN = PER * TPB;
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned span_base;
+    __shared__ unsigned long long wave_e[TPB / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nspan = (nr + SPAN - 1) / SPAN;
+    unsigned long long e = 0;
+    for (uint32_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+        uint32_t mask = 0, cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t r = sp * SPAN + k * TPB + threadIdx.x;
+            if (r < nr && hops[IR[r]] == GT_INF) {
+                const uint32_t c = R2C[r];
+                if (c != 0xFFFFFFFFu) { mask |= 1u << k; cnt++; e += JA[c + 1] - JA[c]; }
+            }
+        }
+        uint32_t inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        if (lane == 63) wave_n[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+            span_base = total ? atomicAdd(list_n, total) : 0u;
+        }
+        __syncthreads();
+        uint32_t o = span_base + wave_n[wave] + inc - cnt;
+        for (uint32_t k = 0; mask; k++, mask >>= 1)
+            if (mask & 1u) list[o++] = sp * SPAN + k * TPB + threadIdx.x;
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    if (lane == 0) wave_e[wave] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; w++) e += wave_e[w]; if (e) atomicAdd(entries, e); }
+}
+// 16 lanes per unreached row: y[r] = min id among its neighbours that are on the current level (bfs.h:52-54, 61-63: the
+// messages of the active columns, min-combined). rows_out[i] = the row if it found one, ~0u if not: position for position,
+// no compaction (nearly every unreached row finds a parent in the steps this is chosen for, and a compaction would be a
+// reservation on one word per 16 rows)
+__global__ void __launch_bounds__(TPB) k_bu_step(const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_dev, const uint32_t *__restrict__ R2C,
+                                                 const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ IR,
+                                                 const uint32_t *__restrict__ hops, uint32_t level, uint32_t vid_base, gt_vidmap vm, uint32_t *__restrict__ y,
+                                                 uint32_t *__restrict__ rows_out) {
+    constexpr uint32_t LPR = 16, GPB = TPB / LPR;
+    const uint32_t n = *n_dev, sub = threadIdx.x & (LPR - 1);
+    for (uint32_t gi = blockIdx.x * GPB + threadIdx.x / LPR; gi < n; gi += gridDim.x * GPB) {
+        uint32_t cand = GT_INF;
+        const uint32_t r = list[gi], c = R2C[r];
+        for (uint32_t e = JA[c] + sub, e1 = JA[c + 1]; e < e1; e += LPR) {
+            const uint32_t u = IR[IA[e]];
+            if (hops[u] == level) { const uint32_t id = gt_vid_of(vm, (uint64_t)vid_base + u); cand = id < cand ? id : cand; }
+        }
+        for (int o = LPR / 2; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(cand, o); cand = t < cand ? t : cand; }
+        if (sub == 0) {
+            const bool found = cand != GT_INF;
+            if (found && cand < y[r]) y[r] = cand;
+            rows_out[gi] = found ? r : 0xFFFFFFFFu;
+        }
+    }
+}
+
 // ---- frontier lists (vertices changed by the last apply)
 __device__ __forceinline__ uint32_t slot_of_vertex(const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ xslot, uint32_t v) {
     if (!(IJ[v] & 2u)) return 0xFFFFFFFFu;   // no column: the vertex sends nothing
@@ -269,6 +337,42 @@ int gt_spmspv_reserve(gt_program *p, uint32_t nact) {
 
 static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done);
 
+// A bottom-up step instead of the push sweep (Beamer's direction switch, with the reference's labels: every neighbour is looked
+// at, the minimum id wins). Only for BFS on a symmetric graph (built with directed = false) on one rank, and only when fewer
+// rows are unreached than vertices are active and the unreached rows' columns hold few entries (counted exactly first).
+static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
+    const gt_graph *g = p->g;
+    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const int mode = menv ? atoi(menv) : -1;   // 0 never, 1 whenever possible, unset: by size
+    const bool dbg = getenv("GRAPHTAP_PB_STATS") != nullptr;
+    if (mode == 0 || !p->fl_enabled || !p->bu_rows || p->prm.kind != GT_BFS || g->flags.directed) return GT_OK;
+    const uint32_t nr = g->info.nnzrows;
+    if (nr == 0) return GT_OK;
+    const uint64_t unreached = nr > p->bfs_settled ? nr - p->bfs_settled : 0;
+    if (dbg) fprintf(stderr, "[bfs] iteration %u: %llu rows unreached (estimate), %llu vertices active\n", p->iteration, (unsigned long long)unreached, (unsigned long long)p->last_active);
+    if (mode != 1 && !(p->last_active != ~0ull && unreached < p->last_active)) return GT_OK;
+    GT_HIP(hipMemsetAsync(p->d_fl + 3, 0, sizeof(unsigned int), s));
+    GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
+    k_bu_collect<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, g->R2C, g->JA, p->s1, nr, p->bu_rows, p->d_fl + 3, p->d_frontier + 1);
+    unsigned long long entries = 0; unsigned int n = 0;
+    GT_HIP(hipMemcpyAsync(&entries, p->d_frontier + 1, sizeof(entries), hipMemcpyDeviceToHost, s));
+    GT_HIP(hipMemcpyAsync(&n, p->d_fl + 3, sizeof(n), hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    if (dbg) fprintf(stderr, "[bfs] iteration %u: %u unreached rows hold %llu entries: %s\n", p->iteration, n, entries, (mode == 1 || entries <= g->info.nnz_local / 8) ? "bottom-up step" : "push sweep");
+    if (mode != 1 && entries > g->info.nnz_local / 8) return GT_OK;   // the push sweep is the cheaper one
+    GT_HIP(hipMemcpyAsync(p->d_fl + 2, p->d_fl + 3, sizeof(unsigned int), hipMemcpyDeviceToDevice, s));   // one slot of fl_rows per unreached row
+    if (n) {
+        const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + TPB / 16 - 1) / (TPB / 16), 256u * 64u);
+        k_bu_step<<<grid, TPB, 0, s>>>(p->bu_rows, p->d_fl + 3, g->R2C, g->JA, g->IA, g->IR, p->s1, p->iteration, g->info.rank * g->info.tile_height,
+                                       gt_vidmap_of(g), (uint32_t *)p->y, p->fl_rows);
+        GT_HIP(hipGetLastError());
+    }
+    p->bottom_up_iters++; p->spmspv_iters++;
+    p->fl_rows_valid = true;
+    *done = true;
+    return GT_OK;
+}
+
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     *done = false;
     const gt_graph *g = p->g;
@@ -279,7 +383,12 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     if (nnz == 0) return GT_OK;
     const bool force = env && atoi(env) == 1;
     p->fl_rows_valid = false;
-    if (p->fl_enabled && p->fl_cur_valid) return spmspv_from_list(p, s, force, done);
+    if (p->fl_enabled && p->fl_cur_valid) {
+        int st = spmspv_from_list(p, s, force, done);
+        if (st != GT_OK || *done) return st;
+    }
+    { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
+    if (p->fl_enabled && p->fl_cur_valid) return GT_OK;
     // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
     // count the converge-mode driver reads anyway) activated few vertices
     static const uint64_t max_active = getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE")) : 16384;

@@ -382,6 +382,34 @@ def test_frontier_lists_are_bit_exact(gt, O, lists, spmspv, known_answers, monke
     if lists == "1": assert got["stats"].list_iterations > 0   # the tail iterations of CC
 
 
+@pytest.mark.parametrize("mode", ["1", "0", None])
+def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, known_answers, monkeypatch):
+    """BFS on a symmetric graph (apps/bfs.cpp loads with directed = false) may run an iteration bottom-up: the unreached rows
+    look at ALL their neighbours and take the minimum id among those on the current level -- what the push sweep's
+    min-combiner (bfs.h:61-63) leaves in y. Parents, hops and iteration counts must be the reference's with the step forced
+    on every iteration (=1), forbidden (=0) and chosen by size (unset); a directed graph never takes it."""
+    from graphtap_amd.rmat import rmat_edges
+    if mode is not None: monkeypatch.setenv("GRAPHTAP_BFS_BOTTOM_UP", mode)
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
+        for root, tag in ((c["root"], ""), (0, "0")) if c["root"] != 0 else ((0, ""),):
+            r = run_min(gt, "bfs", c["edges"], nv, root)
+            assert (r["parent"][:n] == c["np1_bfs%s_a" % tag]).all() and (r["hops"][:n] == c["np1_bfs%s_b" % tag]).all()
+            assert r["iterations"] == k["np1_bfs" + tag]["iterations"]
+            if mode == "1": assert r["stats"].spmspv_iterations == r["iterations"]   # every iteration took a sparse path
+    e = rmat_edges(18, 16, 9); nv = 1 << 18
+    for root in (0, 5, 131071):
+        want = O.run_app("bfs", e, nv, root=root); got = run_min(gt, "bfs", e, nv, root)
+        assert (got["parent"] == want["parent"]).all() and (got["hops"] == want["hops"]).all() and got["iterations"] == want["iterations"]
+    # a DIRECTED graph under the BFS program: the column of a vertex does not list its in-neighbours -- push only
+    G = gt.Graph(); G.load_edges(e, nv, nv, True, False, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.BFS_Program(G, False, False, True, gt._ROW_); P.root = 0; P.execute()
+    og = O.OracleGraph(e, nv, directed=True, transpose=False, self_loops=False, acyclic=False, parallel_edges=False)
+    parent, hops, it = og.bfs(0)
+    assert (P.V["parent"] == parent).all() and (P.V["hops"] == hops).all() and P.iteration == it
+    P.free(); G.free()
+
+
 def test_display_lines_match_survey_table(gt):
     """First states printed by the reference on its bundled sample."""
     c = load_case("rmat10")
