@@ -631,7 +631,10 @@ static int init_common(gt_program *p) {
     // accumulators: init_nonstationary fills y with infinity() (vp:625-635); stationary y is zeroed per combine
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
-    if (!p->stationary && p->prm.order == GT_ROW) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
+    if (!p->stationary && p->prm.order == GT_ROW) {   // frontiers up to the list cap: no allocation inside the iteration loop
+        int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->fl_enabled ? H : p->x_elems, p->fl_enabled ? GT_FRONTIER_CAP : (1u << 20)));
+        if (st != GT_OK) return st;
+    }
     { int st = gt_kernels_preload(s); if (st != GT_OK) return st; }
     p->initialized = true;
     return pr_pack_state(p);
@@ -933,12 +936,10 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
                 const unsigned ga = 1024;   // the length is on the device; the rounds are uniform per workgroup
                 if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
                 else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
-                GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)nr / 32 + 1) * 4, s));
                 p->list_iters++;
             } else {
                 if (nr && bfs) k_apply_rows<true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
                 else if (nr) k_apply_rows<false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
-                if (p->fl_enabled && p->fl_rows_valid) GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)nr / 32 + 1) * 4, s));
                 list_from_flags = lists;   // once the count is known (below)
             }
             p->fl_rows_valid = false;

@@ -176,7 +176,7 @@ struct gt_program {
     std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
 };
 
-#define GT_FRONTIER_CAP (1u << 20)   // longest frontier kept as a list
+#define GT_FRONTIER_CAP (1u << 24)   // longest frontier kept as a list
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
 #ifndef GT_PB_WINDOW
 #define GT_PB_WINDOW 16383u   // columns per DENSE phase-1 window (pb.hip): LDS slot GT_PB_WINDOW holds the neutral message that pad

@@ -156,51 +156,93 @@ __global__ void __launch_bounds__(TPB) k_frontier_list(const uint32_t *__restric
         __syncthreads();   // wave_n / round_base are rewritten by the next round
     }
 }
-// All threads of a workgroup call: the ones with `want` get consecutive positions of `list` (one atomic per workgroup: every
-// reservation hits the same word). Positions at or beyond `cap` are counted but not written -- the host sees the overflow.
-__device__ __forceinline__ void block_append(bool want, uint32_t value, uint32_t *__restrict__ list, unsigned int *__restrict__ cursor, uint32_t cap) {
-    __shared__ unsigned wave_n[TPB / 64];
-    __shared__ unsigned round_base;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t b = __ballot(want);
-    if (lane == 0) wave_n[wave] = (unsigned)__popcll((unsigned long long)b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned total = 0;
-        for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
-        round_base = total ? atomicAdd(cursor, total) : 0u;
-    }
-    __syncthreads();
-    if (want) {
-        const uint32_t o = round_base + wave_n[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-        if (o < cap) list[o] = value;
-    }
-    __syncthreads();   // wave_n / round_base are rewritten by the next call
-}
-
 // one thread per entry of an active column: the column is found by bisection of the entry offsets. EMIT: the rows whose
-// accumulator this pass lowers -- the only rows apply() can change -- go to `rows_out`, once each (mark bits).
+// accumulator this pass lowers -- the only rows apply() can change -- get their bit set in `mark_bits` (k_rows_from_marks turns
+// the bits into the row list). `total_dev` != null: the number of entries is read from the device.
 template <bool WEIGHTED, bool EMIT>
 __global__ void __launch_bounds__(TPB) k_spmspv_min(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ off, uint32_t nact,
-                             uint64_t total, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
-                             uint32_t *__restrict__ y, uint32_t *__restrict__ mark_bits, uint32_t *__restrict__ rows_out, unsigned int *__restrict__ rows_n,
-                             uint32_t rows_cap) {
-    const uint64_t n_round = EMIT ? (total + TPB - 1) / TPB * TPB : total;   // block_append needs every thread in every round
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_round; t += (uint64_t)gridDim.x * blockDim.x) {
-        bool emit = false;
-        uint32_t r = 0;
-        if (t < total) {
-            uint32_t lo = 0, hi = nact;   // last i with off[i] <= t
-            while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
-            const uint32_t e = JA[col[lo]] + (uint32_t)(t - off[lo]);
-            r = IA[e];
-            const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
+                             uint64_t total, const unsigned long long *__restrict__ total_dev, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA,
+                             const uint32_t *__restrict__ A, uint32_t *__restrict__ y, uint32_t *__restrict__ mark_bits) {
+    if (total_dev) total = *total_dev;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nact;   // last i with off[i] <= t
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t e = JA[col[lo]] + (uint32_t)(t - off[lo]);
+        const uint32_t r = IA[e];
+        const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
+        if (m < y[r]) {
+            const uint32_t old = atomicMin(&y[r], m);
+            if (EMIT && m < old) atomicOr(&mark_bits[r >> 5], 1u << (r & 31u));
+        }
+    }
+}
+// eight lanes per active column (no bisection): the columns of a frontier are short -- 1.3 to 8 entries on average in the
+// iterations this path is for; the few long ones (more than `big` entries) are left to the entry-parallel kernel
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(TPB) k_spmspv_cols(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ deg, uint32_t nact,
+                              uint32_t big, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
+                              uint32_t *__restrict__ y, uint32_t *__restrict__ mark_bits) {
+    constexpr uint32_t LPC = 8, GPB = TPB / LPC;
+    const uint32_t sub = threadIdx.x & (LPC - 1);
+    for (uint32_t gi = blockIdx.x * GPB + threadIdx.x / LPC; gi < nact; gi += gridDim.x * GPB) {
+        const uint32_t d = deg[gi];
+        if (d == 0 || d > big) continue;
+        const uint32_t e0 = JA[col[gi]], m0 = val[gi];
+        for (uint32_t k = sub; k < d; k += LPC) {
+            const uint32_t r = IA[e0 + k];
+            const uint32_t m = WEIGHTED ? m0 + A[e0 + k] : m0;
             if (m < y[r]) {
                 const uint32_t old = atomicMin(&y[r], m);
-                if (EMIT && m < old) { const uint32_t bit = 1u << (r & 31u); emit = !(atomicOr(&mark_bits[r >> 5], bit) & bit); }
+                if (m < old) atomicOr(&mark_bits[r >> 5], 1u << (r & 31u));
             }
         }
-        if constexpr (EMIT) block_append(emit, r, rows_out, rows_n, rows_cap);
+    }
+}
+// keeps the entry counts of the long columns only (the others are done) and adds them up
+__global__ void __launch_bounds__(TPB) k_keep_big(uint32_t *__restrict__ deg, uint32_t nact, uint32_t big, unsigned long long *__restrict__ total_big) {
+    unsigned long long e = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nact; i += gridDim.x * blockDim.x) {
+        const uint32_t d = deg[i];
+        if (d > big) e += d; else if (d) deg[i] = 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    __shared__ unsigned long long part[TPB / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; w++) e += part[w]; if (e) atomicAdd(total_big, e); }
+}
+// mark bits -> ascending list of rows; clears the bits. One reservation per 4096 words.
+__global__ void __launch_bounds__(TPB) k_rows_from_marks(uint32_t *__restrict__ mark_bits, uint32_t nwords, uint32_t *__restrict__ rows, unsigned int *__restrict__ rows_n) {
+    constexpr uint32_t PER = 16, SPAN = PER * TPB;
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned span_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nspan = (nwords + SPAN - 1) / SPAN;
+    for (uint32_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+        const uint32_t w0 = sp * SPAN + threadIdx.x * PER;   // 16 consecutive words per thread: its rows come out in order
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) if (w0 + k < nwords) cnt += (uint32_t)__popc(mark_bits[w0 + k]);
+        uint32_t inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        if (lane == 63) wave_n[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int w = 0; w < TPB / 64; w++) { const unsigned n = wave_n[w]; wave_n[w] = total; total += n; }
+            span_base = total ? atomicAdd(rows_n, total) : 0u;
+        }
+        __syncthreads();
+        if (cnt) {
+            uint32_t o = span_base + wave_n[wave] + inc - cnt;
+            for (uint32_t k = 0; k < PER && w0 + k < nwords; k++) {
+                uint32_t m = mark_bits[w0 + k];
+                if (!m) continue;
+                mark_bits[w0 + k] = 0;
+                while (m) { const uint32_t b = (uint32_t)__ffs((int)m) - 1; m &= m - 1; rows[o++] = (w0 + k) * 32 + b; }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -383,11 +425,15 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     if (nnz == 0) return GT_OK;
     const bool force = env && atoi(env) == 1;
     p->fl_rows_valid = false;
+    // BFS with a large frontier and few unreached rows: the bottom-up step first (R-MAT-26, 3.7 M active columns: 0.24 ms against
+    // 0.39 ms for the SpMSpV from the list); small frontiers: the list first
+    const bool bottom_up_first = p->last_active != ~0ull && p->last_active > 65536;
+    if (bottom_up_first) { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
     if (p->fl_enabled && p->fl_cur_valid) {
         int st = spmspv_from_list(p, s, force, done);
         if (st != GT_OK || *done) return st;
     }
-    { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
+    if (!bottom_up_first) { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
     if (p->fl_enabled && p->fl_cur_valid) return GT_OK;
     // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
     // count the converge-mode driver reads anyway) activated few vertices
@@ -403,10 +449,8 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     GT_HIP(hipStreamSynchronize(s));
     if (h[0] == 0 || h[1] == 0) { *done = true; return GT_OK; }  // empty frontier (or active columns without entries here): y keeps its running minima
     // The reference switches at 0.6 of the columns (vp:769). Here the streaming pass already skips every window without an
-    // active column (pb.hip), so the frontier-driven kernel only pays for small frontiers -- measured on BFS / CC / SSSP of
-    // R-MAT-26 (tools/spmspv_sweep.sh, profiles/r02_hubs_first/spmspv_sweep.txt): 4.7 M entries of 3.7 M columns take it
-    // 1.6 ms against 1.0 ms for the streaming pass; the ONE hub column of iteration 0 (1 M entries, nnz / 2000) takes it
-    // 0.17 against 1.5 ms, because that column's window is the heaviest of all. Hence: at most nnz / 1024 entries, and the
+    // active column (pb.hip), so the frontier-driven kernels only pay for small frontiers; this scan-based entry is what is left
+    // when no frontier list exists (several ranks without slices, lists switched off): at most nnz / 1024 entries, and the
     // frontier is only counted when the previous apply activated <= 16 384 vertices.
     static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 1024;
     if (!force && h[1] > nnz / frac) return GT_OK;
@@ -424,9 +468,9 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     }
     const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
     if (p->semiring == GT_MINPLUS_U32)
-        k_spmspv_min<true, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y, nullptr, nullptr, nullptr, 0);
+        k_spmspv_min<true, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], nullptr, g->JA, g->IA, g->A, (uint32_t *)p->y, nullptr);
     else
-        k_spmspv_min<false, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y, nullptr, nullptr, nullptr, 0);
+        k_spmspv_min<false, false><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], nullptr, g->JA, g->IA, nullptr, (uint32_t *)p->y, nullptr);
     GT_HIP(hipGetLastError());
     p->spmspv_iters++;
     *done = true;
@@ -438,6 +482,11 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     const gt_graph *g = p->g;
     const uint32_t nact = p->fl_cur_n;
     if (nact == 0) { *done = true; p->fl_rows_valid = true; GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s)); return GT_OK; }   // nothing is active: y keeps its minima
+    if (!force) {   // counting costs a pass over the list and a round trip (0.15 ms at 8 M vertices): not for a frontier that cannot
+                    // qualify -- the mid-run frontiers hold 8+ entries per vertex, only the tail ones fewer (1.3)
+        static const uint64_t frac0 = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
+        if ((uint64_t)nact * 8 > g->info.nnz_local / frac0) return GT_OK;
+    }
     if (p->fr_cap < nact + 1) { int st = gt_spmspv_reserve(p, nact); if (st != GT_OK) return st; }
     GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
     const unsigned grid = (unsigned)std::min<uint64_t>((nact + TPB - 1) / TPB, 4096);
@@ -448,22 +497,33 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     GT_HIP(hipStreamSynchronize(s));
     GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
     if (h[1] == 0) { *done = true; p->fl_rows_valid = true; return GT_OK; }
-    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 1024;
+    // From the list, with eight lanes per column, the sparse pass wins up to ~nnz/32 entries (tools/spmspv_sweep.sh on R-MAT-26:
+    // 10 M entries of 1.27 M columns 0.41 against 1.49 ms, 4.7 M of 3.7 M columns 0.41 against 0.95 ms, but 102 M entries of
+    // 8.1 M columns 2.1 against 1.8 ms)
+    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
     if (!force && h[1] > g->info.nnz_local / frac) return GT_OK;   // the streaming pass does it (x is complete either way)
     GT_REQUIRE(h[1] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "frontier entry offsets exceed 32 bits");
+    const bool weighted = p->semiring == GT_MINPLUS_U32;
+    uint32_t *marks = (uint32_t *)p->row_mark;
+    // the short columns: eight lanes each
+    constexpr uint32_t BIG = 2048;
+    const unsigned gc = (unsigned)std::min<uint64_t>(((uint64_t)nact + TPB / 8 - 1) / (TPB / 8), 256u * 64u);
+    if (weighted) k_spmspv_cols<true><<<gc, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, BIG, g->JA, g->IA, g->A, (uint32_t *)p->y, marks);
+    else k_spmspv_cols<false><<<gc, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, BIG, g->JA, g->IA, nullptr, (uint32_t *)p->y, marks);
+    // the long ones (hubs): one thread per entry
+    k_keep_big<<<grid, TPB, 0, s>>>(p->fr_off, nact, BIG, p->d_frontier + 2);
     {
         size_t tb = 0;
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, nact, s));
         if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
     }
-    const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
-    if (p->semiring == GT_MINPLUS_U32)
-        k_spmspv_min<true, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, g->A, (uint32_t *)p->y,
-                                                    (uint32_t *)p->row_mark, p->fl_rows, p->d_fl + 2, p->fl_rows_cap);
-    else
-        k_spmspv_min<false, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, h[1], g->JA, g->IA, nullptr, (uint32_t *)p->y,
-                                                     (uint32_t *)p->row_mark, p->fl_rows, p->d_fl + 2, p->fl_rows_cap);
+    const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 16u);   // at most h[1] entries are long columns'; the kernel reads the exact count
+    if (weighted) k_spmspv_min<true, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, 0, p->d_frontier + 2, g->JA, g->IA, g->A, (uint32_t *)p->y, marks);
+    else k_spmspv_min<false, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, 0, p->d_frontier + 2, g->JA, g->IA, nullptr, (uint32_t *)p->y, marks);
+    // the rows either kernel lowered, in ascending order
+    const uint32_t nwords = g->info.nnzrows / 32 + 1;
+    k_rows_from_marks<<<(unsigned)std::min<uint64_t>(((uint64_t)nwords + 4095) / 4096, 4096), TPB, 0, s>>>(marks, nwords, p->fl_rows, p->d_fl + 2);
     GT_HIP(hipGetLastError());
     p->spmspv_iters++;
     p->fl_rows_valid = true;
