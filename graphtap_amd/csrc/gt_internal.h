@@ -165,6 +165,9 @@ struct gt_program {
     uint32_t *bu_rows = nullptr;              // [nnzrows] rows of unreached vertices
     uint64_t bfs_settled = 0;                 // rows reached so far (host estimate from the active counts)
     uint32_t bottom_up_iters = 0;
+    // a bottom-up step reads no messages: scatter_gather() defers the messenger when such a step is likely, combine runs it
+    // after all if the step is declined, and x is marked stale (the next messenger rewrites all of it) if it was not needed
+    bool x_deferred = false, x_stale = false;
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
     bool cf_hint = false;
@@ -238,7 +241,9 @@ inline gt_vidmap gt_vidmap_of(const gt_graph *g) { return gt_vidmap{g->perm_ainv
 int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
 // the messenger over the frontier lists: resets the slots of the previous frontier, writes the messages of the current one
 int gt_frontier_messages(gt_program *p, hipStream_t s);
-int gt_kernels_preload(hipStream_t s);   // loads the code object of kernels.hip (called by initialize)
+int gt_kernels_preload(hipStream_t s);
+bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
+extern "C" int gt_min_messenger(gt_program *p);      // the messenger of BFS / SSSP / CC, now (engine.hip, inside its extern "C" block; not part of the ABI header)   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the

@@ -382,17 +382,25 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
 // A bottom-up step instead of the push sweep (Beamer's direction switch, with the reference's labels: every neighbour is looked
 // at, the minimum id wins). Only for BFS on a symmetric graph (built with directed = false) on one rank, and only when fewer
 // rows are unreached than vertices are active and the unreached rows' columns hold few entries (counted exactly first).
-static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
+bool gt_bfs_bottom_up_likely(const gt_program *p) {
     const gt_graph *g = p->g;
     const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
     const int mode = menv ? atoi(menv) : -1;   // 0 never, 1 whenever possible, unset: by size
+    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    if (mode == 0 || (senv && atoi(senv) == 0) || !p->fl_enabled || !p->bu_rows || p->prm.kind != GT_BFS || g->flags.directed || g->info.nnzrows == 0) return false;
+    const uint64_t nr = g->info.nnzrows, unreached = nr > p->bfs_settled ? nr - p->bfs_settled : 0;
+    return mode == 1 || (p->last_active != ~0ull && unreached < p->last_active);
+}
+
+static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
+    const gt_graph *g = p->g;
+    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const int mode = menv ? atoi(menv) : -1;
     const bool dbg = getenv("GRAPHTAP_PB_STATS") != nullptr;
-    if (mode == 0 || !p->fl_enabled || !p->bu_rows || p->prm.kind != GT_BFS || g->flags.directed) return GT_OK;
+    if (!gt_bfs_bottom_up_likely(p)) return GT_OK;
     const uint32_t nr = g->info.nnzrows;
-    if (nr == 0) return GT_OK;
-    const uint64_t unreached = nr > p->bfs_settled ? nr - p->bfs_settled : 0;
-    if (dbg) fprintf(stderr, "[bfs] iteration %u: %llu rows unreached (estimate), %llu vertices active\n", p->iteration, (unsigned long long)unreached, (unsigned long long)p->last_active);
-    if (mode != 1 && !(p->last_active != ~0ull && unreached < p->last_active)) return GT_OK;
+    if (dbg) fprintf(stderr, "[bfs] iteration %u: %llu rows unreached (estimate), %llu vertices active\n", p->iteration,
+                     (unsigned long long)(nr > p->bfs_settled ? nr - p->bfs_settled : 0), (unsigned long long)p->last_active);
     GT_HIP(hipMemsetAsync(p->d_fl + 3, 0, sizeof(unsigned int), s));
     GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
     k_bu_collect<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, g->R2C, g->JA, p->s1, nr, p->bu_rows, p->d_fl + 3, p->d_frontier + 1);
@@ -439,6 +447,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     // count the converge-mode driver reads anyway) activated few vertices
     static const uint64_t max_active = getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE")) : 16384;
     if (!force && p->last_active > max_active) return GT_OK;
+    if (p->x_deferred) { int st = gt_min_messenger(p); if (st != GT_OK) return st; }   // this path scans x
     if (!p->d_frontier) { int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->x_elems, 1u << 20)); if (st != GT_OK) return st; }
     GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
     const uint32_t x_len = (uint32_t)p->x_elems;
