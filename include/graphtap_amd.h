@@ -254,7 +254,10 @@ int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int re
  * rank it is written by scatter_gather directly. On several ranks scatter_gather fills the SEND buffer
  * (gt_program_send, send_elems elements of the same type) and the driver moves it into every rank's x with the K
  * all-to-alls of gt_graph_exchange_plan. The engine owns default buffers; a caller that exchanges through its own
- * allocations (torch tensors handed to RCCL) installs them with gt_program_set_x / gt_program_set_send. */
+ * allocations (torch tensors handed to RCCL) installs them with gt_program_set_x / gt_program_set_send.
+ * One rank, BFS on a symmetric graph: an iteration that is likely to run bottom-up (it reads vertex states, not messages)
+ * does not write x in scatter_gather -- combine does if it takes the push sweep after all; GRAPHTAP_BFS_BOTTOM_UP=0 for
+ * callers that want x after every scatter_gather. */
 int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
 int gt_program_set_x(gt_program *p, void *dev_ptr);
 int gt_program_send(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
