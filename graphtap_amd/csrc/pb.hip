@@ -606,7 +606,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // straight to VAL (each covering a strided subset of the group's ~1 KiB of slots) were bound by the write REQUESTS they
     // make, not by bytes or instructions -- a second DPP scan added to the kernel cost nothing, staging the outputs through
     // this row and storing 64 consecutive slots per instruction gave 8 % (1.69 -> 1.55 ms per SpMV)
-    __shared__ TV stage[P1_THREADS / 64][256];
+    // The min programs keep the direct stores: on their graphs (symmetrised, twice the bins and runs, more run heads per group)
+    // the staged form is 10-20 % SLOWER (CC R-MAT-26: 3.39 -> 4.06 ms for a full pass), measured by A/B on one box.
+    constexpr bool STAGED = !IS_MIN;
+    __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 1];
     const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)
     // ONE launch for both kinds of chunks (dense ones first, largest first; the light sparse ones fill the tail): two launches
@@ -671,6 +674,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // what the quad leaves open for the lanes above: everything when it holds no end, else what follows its last end
             const TV carry = wave_carry<TV, IS_MIN>(e3 ? neutral : a3, has_end);
             // the quad's first end also closes what the lanes below left open
+            if constexpr (!STAGED) {   // every lane stores its outputs itself: the k-slots of a wave's outputs are consecutive
+                const uint32_t k0 = i0 + delta;
+                if (e0) *reinterpret_cast<TV *>(VALb + (size_t)(k0 * (uint32_t)sizeof(TV))) = comb(carry, v0);
+                if (e1) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n0) * (uint32_t)sizeof(TV))) = n0 ? a1 : comb(carry, a1);
+                if (e2) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n1) * (uint32_t)sizeof(TV))) = n1 ? a2 : comb(carry, a2);
+                if (e3) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n2) * (uint32_t)sizeof(TV))) = n2 ? a3 : comb(carry, a3);
+                continue;
+            }
             TV *__restrict__ st = stage[wave];
             if (e0) st[i0] = comb(carry, v0);
             if (e1) st[i0 + n0] = n0 ? a1 : comb(carry, a1);
