@@ -869,8 +869,11 @@ int gt_layout_build(gt_graph *g) {
     // Hub = a column with at least `thr` entries: its window is worth the aggregating kernel. R-MAT-26: the 1.05 M columns of
     // degree >= 100 hold 73 % of the entries and 4.3 entries per (window, row) pair; columns below ~20 entries sit in windows
     // with 1.0x entries per pair, where the aggregation machinery only costs (tools/layout_stats.py).
+    // Since the outputs of the plus kernels leave through the staged stores a sparsely filled dense window costs less: 12
+    // instead of 24 is 393 M instead of 400 M slots on R-MAT-26 and ~3 % (PageRank 1.59 -> 1.54 ms, A/B); the weighted graphs
+    // (SSSP: direct stores) keep 24, where 12 was 3-4 % slower; BFS / CC are indifferent.
     const char *et = getenv("GRAPHTAP_PB_HUB_DEG");
-    const uint32_t thr = et ? (uint32_t)atoi(et) : 24u;
+    const uint32_t thr = et ? (uint32_t)atoi(et) : (g->info.weighted ? 24u : 12u);
     struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } deg, hubflag, tailflag, hubpos, tailpos, key, key2, col, col2, tmp;
     for (Buf *b : {&deg, &hubflag, &tailflag, &hubpos, &tailpos}) LAY_HIP(hipMalloc(&b->p, (uint64_t)(nc + 1) * 4));
     LAY_HIP(hipMemsetAsync(hubflag.p, 0, (uint64_t)(nc + 1) * 4, s));
