@@ -606,8 +606,8 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // straight to VAL (each covering a strided subset of the group's ~1 KiB of slots) were bound by the write REQUESTS they
     // make, not by bytes or instructions -- a second DPP scan added to the kernel cost nothing, staging the outputs through
     // this row and storing 64 consecutive slots per instruction gave 8 % (1.69 -> 1.55 ms per SpMV)
-    // The min programs keep the direct stores: on their graphs (symmetrised, twice the bins and runs, more run heads per group)
-    // the staged form is 10-20 % SLOWER (CC R-MAT-26: 3.39 -> 4.06 ms for a full pass), measured by A/B on one box.
+    // The min programs keep the direct stores: the staged form is 10-20 % SLOWER for them (CC R-MAT-26: 3.39 -> 4.06 ms for a
+    // full pass), measured by A/B on one box; neither occupancy nor the number of run heads explains it.
     constexpr bool STAGED = !IS_MIN;
     __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 1];
     const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
