@@ -58,7 +58,8 @@ class ExecStats(C.Structure):
                 ("scatter_gather_ms", C.c_double), ("combine_ms", C.c_double), ("apply_ms", C.c_double),
                 ("spmspv_iterations", C.c_uint32), ("phase_samples", C.c_uint32),
                 ("scatter_gather_sq", C.c_double), ("combine_sq", C.c_double), ("apply_sq", C.c_double),
-                ("cf_filtered_iterations", C.c_uint32), ("list_iterations", C.c_uint32)]
+                ("cf_filtered_iterations", C.c_uint32), ("list_iterations", C.c_uint32),
+                ("allocs_in_execute", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 # every symbol include/graphtap_amd.h declares: (restype, argtypes)
@@ -132,7 +133,7 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        if L.gt_abi_version() != 1:
+        if L.gt_abi_version() != 2:
             raise GraphTapError("ABI version mismatch")
         _lib = L
     return _lib

@@ -538,7 +538,8 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
         p->fl_enabled = !p->stationary && !gt_has_exchange(g) && g->info.nranks == 1 && !(fe && atoi(fe) == 0);
         if (ok && p->fl_enabled) {
             p->fl_rows_cap = std::max<uint32_t>(g->info.nnzrows, 1);
-            ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)GT_FRONTIER_CAP * 4) == hipSuccess &&
+            p->fl_cap = std::max<uint32_t>(std::min<uint32_t>(H, GT_FRONTIER_CAP), 1);   // a list never holds more than the segment's H vertices
+            ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)p->fl_cap * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)p->fl_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->fl_rows, (uint64_t)p->fl_rows_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess;
             if (ok && prm->kind == GT_BFS && !g->flags.directed)   // symmetric graph: bottom-up steps are possible (kernels.hip)
@@ -632,7 +633,11 @@ static int init_common(gt_program *p) {
     if (!p->stationary) k_fill<uint32_t><<<grid_for(p->y_elems), TPB, 0, s>>>((uint32_t *)p->y, p->y_elems, GT_INF);
     GT_HIP(hipGetLastError());
     if (!p->stationary && p->prm.order == GT_ROW) {   // frontiers up to the list cap: no allocation inside the iteration loop
-        int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->fl_enabled ? H : p->x_elems, p->fl_enabled ? GT_FRONTIER_CAP : (1u << 20)));
+        int st = gt_spmspv_reserve(p, (uint32_t)std::min<uint64_t>(p->fl_enabled ? H : p->x_elems, p->fl_enabled ? p->fl_cap : (1u << 20)));
+        if (st != GT_OK) return st;
+    }
+    if (g->spmv_variant != GT_SPMV_EDGE && g->pb && p->prm.order == GT_ROW) {   // the value stream of the SpMV this program runs: not inside execute()
+        int st = gt_pb_reserve_val(g, (p->prm.kind == GT_PR && !p->x_f32) ? 8u : 4u, s);
         if (st != GT_OK) return st;
     }
     { int st = gt_kernels_preload(s); if (st != GT_OK) return st; }
@@ -952,8 +957,8 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
                 if (!p->fl_cur_valid) GT_HIP(hipMemsetAsync(p->C, 0, H, s));
                 else if (p->fl_cur_n) k_list_clear_flags<<<gl, TPB, 0, s>>>(p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur);
                 const unsigned ga = 1024;   // the length is on the device; the rounds are uniform per workgroup
-                if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
-                else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, GT_FRONTIER_CAP);
+                if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap);
+                else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap);
                 p->list_iters++;
             } else {
                 if (nr && bfs) k_apply_rows<true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
@@ -977,10 +982,10 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     if (p->fl_enabled && !p->stationary) {   // the list of the vertices this apply changed becomes the current frontier
         p->fl_prev_valid = p->fl_cur_valid; p->fl_prev_n = p->fl_cur_n;
         p->fl_cur ^= 1;
-        p->fl_cur_valid = active != nullptr && p->last_active <= GT_FRONTIER_CAP;
+        p->fl_cur_valid = active != nullptr && p->last_active <= p->fl_cap;
         p->fl_cur_n = p->fl_cur_valid ? (uint32_t)p->last_active : 0;
         if (p->fl_cur_valid && list_from_flags && nr && p->fl_cur_n)   // a full apply that changed few: collect them
-            k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur, GT_FRONTIER_CAP);
+            k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur, p->fl_cap);
         GT_HIP(hipGetLastError());
     }
     return GT_OK;
@@ -1005,8 +1010,10 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->spmspv_allocs = 0;
     GT_HIP(hipStreamSynchronize(s));
+    const uint32_t val_allocs0 = gt_pb_val_allocs(p->g);
+    const size_t ev0 = p->ev.size();
     auto t0 = std::chrono::steady_clock::now();
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
     // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
@@ -1046,6 +1053,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->scatter_gather_sq = q_sg; stats->combine_sq = q_cb; stats->apply_sq = q_ap; stats->phase_samples = samples;
         stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
         stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = p->list_iters;
+        stats->allocs_in_execute = (gt_pb_val_allocs(p->g) - val_allocs0) + p->spmspv_allocs + (uint32_t)(p->ev.size() - ev0);
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

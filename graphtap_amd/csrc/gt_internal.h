@@ -146,12 +146,14 @@ struct gt_program {
     uint32_t fr_cap = 0;
     unsigned long long *d_frontier = nullptr;                           // [2] active columns, entries in them
     uint64_t last_active = ~0ull;                                       // vertices the previous apply() activated (converge mode), or ~0 if unknown
+    uint32_t spmspv_allocs = 0;                                         // allocations gt_spmspv_reserve made since execute() began (0 after initialize reserved)
     uint32_t spmspv_iters = 0;                                          // iterations of the current execute() that took the sparse path
     // FRONTIER LISTS (min programs on one rank, converge mode): every apply() appends the vertices it changes to a list; while that
     // list is short (<= GT_FRONTIER_CAP) the next iteration never walks a full vector -- the messenger resets the previous
     // frontier's slots of x and writes the new ones, the SpMSpV takes its columns from the list and emits the rows it lowers
     // (de-duplicated through row_mark), and apply() visits those rows only (engine.hip, kernels.hip).
-    uint32_t *fl_v[2] = {nullptr, nullptr};   // [GT_FRONTIER_CAP] vertex lists: fl_v[fl_cur] = vertices changed by the last apply
+    uint32_t fl_cap = 0;                      // min(H, GT_FRONTIER_CAP): elements of each list
+    uint32_t *fl_v[2] = {nullptr, nullptr};   // [fl_cap] vertex lists: fl_v[fl_cur] = vertices changed by the last apply
     uint32_t *fl_rows = nullptr;              // [fl_rows_cap] rows the SpMSpV of this iteration lowered
     uint8_t *row_mark = nullptr;              // [nnzrows] 1 = already in fl_rows (zero between iterations)
     unsigned int *d_fl = nullptr;             // [4] device counters: elements of fl_v[0], fl_v[1], fl_rows
@@ -211,6 +213,8 @@ uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
                const gt_pr_epilogue *epi = nullptr, bool skip_source = false);
+int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s);   // allocates + touches VAL (initialize time)
+uint32_t gt_pb_val_allocs(const gt_graph *g);   // how many times VAL was (re)allocated so far
 uint64_t gt_pb_source_entries(const gt_graph *g);   // entries in chunks of source rows (left out by PageRank/TCSC_CF until the last iteration)
 
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);

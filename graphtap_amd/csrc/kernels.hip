@@ -363,8 +363,9 @@ __global__ void k_list_frontier(const uint32_t *__restrict__ list, uint32_t n, c
 // buffers of the sparse path, sized for frontiers of up to `nact` columns (called at initialize() so that no allocation
 // falls into the iteration loop)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact) {
-    if (!p->d_frontier) GT_HIP(hipMalloc((void **)&p->d_frontier, 4 * sizeof(unsigned long long)));
+    if (!p->d_frontier) { GT_HIP(hipMalloc((void **)&p->d_frontier, 4 * sizeof(unsigned long long))); p->spmspv_allocs++; }
     if (p->fr_cap < nact + 1) {
+        p->spmspv_allocs += 3;
         for (void *q : {(void *)p->fr_col, (void *)p->fr_val, (void *)p->fr_off}) if (q) GT_HIP(hipFree(q));
         p->fr_col = p->fr_val = p->fr_off = nullptr; p->fr_cap = 0;
         const uint64_t cap = (uint64_t)nact + nact / 2 + 1024;
@@ -373,7 +374,7 @@ int gt_spmspv_reserve(gt_program *p, uint32_t nact) {
     }
     size_t tb = 0;
     GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, p->fr_cap, (hipStream_t)0));
-    if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+    if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; p->spmspv_allocs++; }
     return GT_OK;
 }
 
@@ -472,7 +473,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     {   // degrees -> exclusive offsets, in place
         size_t tb = 0;
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, nact, s));
-        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; p->spmspv_allocs++; }
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
     }
     const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 64u);
@@ -524,7 +525,7 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     {
         size_t tb = 0;
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, p->fr_off, p->fr_off, nact, s));
-        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; }
+        if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; p->spmspv_allocs++; }
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
     }
     const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 16u);   // at most h[1] entries are long columns'; the kernel reads the exact count

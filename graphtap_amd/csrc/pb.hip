@@ -40,6 +40,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -478,6 +479,45 @@ template <> struct Msg<double, double> { static __device__ __forceinline__ doubl
 template <> struct Msg<double, float> { static __device__ __forceinline__ float val(float x, uint32_t) { return x; } };
 template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
 
+// Loads of the once-read streams (LCOL, WT, group records in phase 1; VAL, LROW in phase 2) and stores of the once-written
+// value stream: NON-TEMPORAL. tools/hbm_ceiling2.hip on this pool: a read stream of contiguous per-workgroup spans runs at
+// 6.1 TB/s with default-policy loads and at 7.1-7.2 TB/s with nt loads (LDS-DMA nt: 7.0-7.3); writes 5.4-5.8 either way.
+#ifndef GT_PB_NT
+#define GT_PB_NT 1
+#endif
+typedef uint32_t gt_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t gt_u32x4 __attribute__((ext_vector_type(4)));
+template <class S> __device__ __forceinline__ S ld_stream(const S *__restrict__ p) {
+#if GT_PB_NT
+    if constexpr (sizeof(S) == 4) { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); return __builtin_bit_cast(S, v); }
+    else if constexpr (sizeof(S) == 8) { const gt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x2 *>(p)); return __builtin_bit_cast(S, v); }
+    else if constexpr (sizeof(S) == 16) { const gt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p)); return __builtin_bit_cast(S, v); }
+    else {
+        static_assert(sizeof(S) == 32, "stream element of 4, 8, 16 or 32 bytes");
+        struct P2 { gt_u32x4 a, b; } v;
+        v.a = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p)); v.b = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p) + 1);
+        return __builtin_bit_cast(S, v);
+    }
+#else
+    return *p;
+#endif
+}
+template <class S> __device__ __forceinline__ void st_stream(S *__restrict__ p, const S &x) {
+#if GT_PB_NT >= 2
+    if constexpr (sizeof(S) == 4) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, x), reinterpret_cast<uint32_t *>(p));
+    else if constexpr (sizeof(S) == 8) __builtin_nontemporal_store(__builtin_bit_cast(gt_u32x2, x), reinterpret_cast<gt_u32x2 *>(p));
+    else if constexpr (sizeof(S) == 16) __builtin_nontemporal_store(__builtin_bit_cast(gt_u32x4, x), reinterpret_cast<gt_u32x4 *>(p));
+    else {
+        static_assert(sizeof(S) == 32, "stream element of 4, 8, 16 or 32 bytes");
+        struct P2 { gt_u32x4 a, b; };
+        const P2 v = __builtin_bit_cast(P2, x);
+        __builtin_nontemporal_store(v.a, reinterpret_cast<gt_u32x4 *>(p)); __builtin_nontemporal_store(v.b, reinterpret_cast<gt_u32x4 *>(p) + 1);
+    }
+#else
+    *p = x;
+#endif
+}
+
 template <class TV> struct alignas(sizeof(TV) * 4 > 16 ? 16 : sizeof(TV) * 4) V4 { TV a[4]; };
 struct alignas(8) C4 { uint16_t c[4]; };
 template <class WTy> struct alignas(sizeof(WTy) * 4) WQ { WTy w[4]; };   // the weights of a quad: 4, 8 or 16 bytes
@@ -635,9 +675,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         for (int u = 0; u < U; u++) {
             const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
             const uint32_t q = g * 64 + lane;
-            olc[u] = LCOL4[q];                                    // 8 B/lane
-            ogw[u] = Gw[(uint64_t)g * 8 + (lane & 7)];            // lane i holds dword i & 7 of the 32-byte group record
-            if constexpr (WEIGHTED) ow[u] = WT4[q]; else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
+            olc[u] = ld_stream(LCOL4 + q);                        // 8 B/lane
+            ogw[u] = ld_stream(Gw + ((uint64_t)g * 8 + (lane & 7)));   // lane i holds dword i & 7 of the 32-byte group record
+            if constexpr (WEIGHTED) ow[u] = ld_stream(WT4 + q); else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
         }
     };
     uint32_t g0 = (q0c >> 6) + wave * U;
@@ -653,7 +693,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                 V4<TV> o;
 #pragma unroll
                 for (int j = 0; j < 4; j++) o.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & COLMASK], w[u].w[j]);
-                *reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)) = o;   // runs start at multiples of four slots in both orders
+                st_stream(reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)), o);   // runs start at multiples of four slots in both orders
                 continue;
             }
             // output-end bits of the quad
@@ -676,10 +716,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // the quad's first end also closes what the lanes below left open
             if constexpr (!STAGED) {   // every lane stores its outputs itself: the k-slots of a wave's outputs are consecutive
                 const uint32_t k0 = i0 + delta;
-                if (e0) *reinterpret_cast<TV *>(VALb + (size_t)(k0 * (uint32_t)sizeof(TV))) = comb(carry, v0);
-                if (e1) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n0) * (uint32_t)sizeof(TV))) = n0 ? a1 : comb(carry, a1);
-                if (e2) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n1) * (uint32_t)sizeof(TV))) = n1 ? a2 : comb(carry, a2);
-                if (e3) *reinterpret_cast<TV *>(VALb + (size_t)((k0 + n2) * (uint32_t)sizeof(TV))) = n2 ? a3 : comb(carry, a3);
+                if (e0) st_stream(reinterpret_cast<TV *>(VALb + (size_t)(k0 * (uint32_t)sizeof(TV))), comb(carry, v0));
+                if (e1) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n0) * (uint32_t)sizeof(TV))), n0 ? a1 : comb(carry, a1));
+                if (e2) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n1) * (uint32_t)sizeof(TV))), n1 ? a2 : comb(carry, a2));
+                if (e3) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n2) * (uint32_t)sizeof(TV))), n2 ? a3 : comb(carry, a3));
                 continue;
             }
             TV *__restrict__ st = stage[wave];
@@ -698,7 +738,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                     const uint32_t S = __builtin_amdgcn_readlane(i0, hl), D = __builtin_amdgcn_readlane(delta, hl);
                     d = i >= S ? D : d;
                 }
-                *reinterpret_cast<TV *>(VALb + (size_t)((i + d) * (uint32_t)sizeof(TV))) = st[i];
+                st_stream(reinterpret_cast<TV *>(VALb + (size_t)((i + d) * (uint32_t)sizeof(TV))), (TV)st[i]);
             }
         }
         g0 = gn;
@@ -733,14 +773,14 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     for (; q + (P2_U - 1) * P2_THREADS < qb; q += P2_U * P2_THREADS) {
         C4 r[P2_U]; V4<TV> a[P2_U];
 #pragma unroll
-        for (int u = 0; u < P2_U; u++) { r[u] = LROW4[q + u * P2_THREADS]; a[u] = VAL4[q + u * P2_THREADS]; }
+        for (int u = 0; u < P2_U; u++) { r[u] = ld_stream(LROW4 + (q + u * P2_THREADS)); a[u] = ld_stream(VAL4 + (q + u * P2_THREADS)); }
 #pragma unroll
         for (int u = 0; u < P2_U; u++)
 #pragma unroll
             for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r[u].c[j], (T)a[u].a[j]);
     }
     for (; q < qb; q += P2_THREADS) {
-        const C4 r0 = LROW4[q]; const V4<TV> a0 = VAL4[q];
+        const C4 r0 = ld_stream(LROW4 + q); const V4<TV> a0 = ld_stream(VAL4 + q);
 #pragma unroll
         for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
     }
@@ -830,6 +870,8 @@ struct gt_pb {
     std::vector<uint32_t> slice_chunk;   // chunks of slice k of the message vector: [slice_chunk[k], slice_chunk[k+1])
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
+    uint32_t val_cap = 0;      // bytes per slot VAL was allocated for (gt_pb_reserve_val)
+    uint32_t val_allocs = 0;   // allocations of VAL so far (gt_exec_stats.allocs_in_execute counts those made inside execute())
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice (and kind), largest chunk first
     uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
@@ -1267,6 +1309,28 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     return GT_OK;
 }
 
+// The value stream is allocated (and touched once) where programs are initialized, never inside the iteration loop: a
+// multi-GB hipMalloc stalls for seconds now and then on this pool, and the first streaming pass of a min program -- BFS's
+// iteration 1, iteration 0 takes the SpMSpV -- used to pay for it inside execute().
+int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s) {
+    gt_pb *pb = g->pb;
+    if (!pb || pb->nnz == 0 || pb->val_cap >= bytes_per_slot) return GT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (pb->VAL) gt_scratch_free(pb->VAL);
+    pb->VAL = nullptr; pb->val_cap = 0; pb->val_bytes = 0; pb->val_kind = 0;
+    const uint64_t bytes = (uint64_t)std::max(pb->nout, 4u) * bytes_per_slot;
+    if (gt_scratch_malloc(&pb->VAL, bytes) != hipSuccess) { pb->VAL = nullptr; gt_set_error("out of device memory for the value stream (%llu bytes)", (unsigned long long)bytes); return GT_ERR_HIP; }
+    GT_HIP(hipMemsetAsync(pb->VAL, 0, bytes, s));   // first touch here, not in the first SpMV
+    pb->val_cap = bytes_per_slot; pb->val_allocs++;
+    if (getenv("GRAPHTAP_PB_STATS")) {
+        GT_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[build] value stream: %.2f GB (%u B x %u slots) allocated and touched in %.1f ms\n", bytes / 1e9, bytes_per_slot, pb->nout,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return GT_OK;
+}
+uint32_t gt_pb_val_allocs(const gt_graph *g) { return g->pb ? g->pb->val_allocs : 0; }
+
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
 const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n) { *n = g->pb ? g->pb->nsplit : 0; return g->pb ? g->pb->split_bins : nullptr; }
 uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
@@ -1284,11 +1348,8 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     const uint32_t need = (semiring == GT_PLUS_F64 && !f32_messages) ? 8 : 4;
     const int kind = (semiring == GT_PLUS_F64) ? (f32_messages ? 1 : 2) : 3;
     if ((phases & GT_PB_PREPARE) && (pb->val_bytes != need || pb->val_kind != kind)) {
-        if (pb->val_bytes < need) {
-            if (pb->VAL) GT_HIP(hipFree(pb->VAL));
-            pb->VAL = nullptr; pb->val_bytes = 0;
-            GT_HIP(hipMalloc(&pb->VAL, (uint64_t)std::max(pb->nout, 4u) * need));
-        }
+        // programs reserve the stream in initialize() (gt_pb_reserve_val): this allocates only for a bare gt_spmv
+        { int st = gt_pb_reserve_val(g, need, s); if (st != GT_OK) return st; }
         pb->val_bytes = need; pb->val_kind = kind; pb->val_min = -1; pb->val_owner = nullptr;   // re-fill for the new element type
     }
     switch (semiring) {

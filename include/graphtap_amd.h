@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 1
+#define GT_ABI_VERSION 2 /* 2: gt_exec_stats grew (round 2: five fields; round 3: allocs_in_execute), gt_dist_* and gt_spmv_cf added */
 #define GT_INF 2147483647u /* apps/bfs.h:12 */
 
 typedef enum gt_status {
@@ -177,6 +177,9 @@ typedef struct gt_exec_stats {
                                         filtering, compressed_column.hpp:671-708, vp:1264-1317: all but the last iteration) */
     uint32_t list_iterations;        /* BFS / SSSP / CC on one rank: iterations whose three phases all ran on frontier lists (messenger over
                                         the changed vertices, SpMSpV over their columns, apply over the rows it lowered) */
+    uint32_t allocs_in_execute;      /* device allocations made inside the iteration loop of this call (0: everything the loop needs
+                                        is reserved by initialize(); a bare gt_spmv on a graph no program touched may allocate) */
+    uint32_t reserved0;
 } gt_exec_stats;
 
 /* state fields for gt_program_copy_state */

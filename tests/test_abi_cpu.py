@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
-    assert _lib.lib().gt_abi_version() == 1
+    assert _lib.lib().gt_abi_version() == 2
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(tmp_path):
     from graphtap_amd import _lib
     pairs = [("gt_graph_flags", _lib.GraphFlags, "parallel_edges"), ("gt_graph_info", _lib.GraphInfo, "send_elems"),
              ("gt_tile_arrays", _lib.TileArrays, "L2G"), ("gt_exchange_plan", _lib.ExchangePlan, "recv_counts"),
-             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "list_iterations")]
+             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "reserved0")]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "graphtap_amd.h"\nint main(void){' +
                    "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, m) for c, _, m in pairs) + "return 0;}")
@@ -44,7 +44,7 @@ def test_struct_layouts_match_header(tmp_path):
     for (cname, cls, member), line in zip(pairs, lines):
         size, off = map(int, line.split())
         assert C.sizeof(cls) == size and getattr(cls, member).offset == off, cname
-    assert C.sizeof(_lib.GraphInfo) == 96 and C.sizeof(_lib.ExecStats) == 96
+    assert C.sizeof(_lib.GraphInfo) == 96 and C.sizeof(_lib.ExecStats) == 104
 
 
 def test_no_cpu_fallback_without_a_gpu():

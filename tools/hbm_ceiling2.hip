@@ -1,0 +1,147 @@
+// hbm_ceiling2.hip -- the guide-shaped streaming kernels (MI355X_MICROARCH.md: 6.29 TB/s float4 copy, 6.4-6.8 TB/s
+// nt / LDS-DMA streams) on THIS pool: persistent grids (CUs x k workgroups), 16 B per lane, U loads in flight per
+// lane, default cache policy against __builtin_nontemporal_load/store, and an LDS-DMA (global_load_lds_dwordx4) read.
+// Output kept under profiles/ (VERDICT round 2, item 1a).
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/hbm_ceiling2 tools/hbm_ceiling2.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// every workgroup owns a contiguous span of the buffer; a wave walks it in pieces of U x 1 KiB-per-wave-instruction
+// (BLOCKED) or the classic grid-stride interleave (!BLOCKED)
+template <int U, bool NT, bool BLOCKED>
+__global__ void __launch_bounds__(256) k_read(const v4f *__restrict__ a, uint64_t n, float *out) {
+    v4f s = {0, 0, 0, 0};
+    if (BLOCKED) {
+        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+        const uint64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += (uint64_t)blockDim.x * U) {
+            v4f v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint64_t j = i + (uint64_t)u * blockDim.x;
+                if (j < hi) v[u] = NT ? __builtin_nontemporal_load(a + j) : a[j]; else v[u] = s;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) s += v[u];
+        }
+    } else {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride * U) {
+            v4f v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint64_t j = i + u * stride;
+                if (j < n) v[u] = NT ? __builtin_nontemporal_load(a + j) : a[j]; else v[u] = s;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) s += v[u];
+        }
+    }
+    if (s.x + s.y + s.z + s.w == 1.2345e30f) *out = s.x;
+}
+
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_write(v4f *__restrict__ a, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const v4f one = {1, 2, 3, 4};
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride * U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t j = i + u * stride;
+            if (j < n) { if (NT) __builtin_nontemporal_store(one, a + j); else a[j] = one; }
+        }
+    }
+}
+
+template <int U, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) k_copy(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride * U) {
+        v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { uint64_t j = i + u * stride; if (j < n) v[u] = NTL ? __builtin_nontemporal_load(a + j) : a[j]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { uint64_t j = i + u * stride; if (j < n) { if (NTS) __builtin_nontemporal_store(v[u], b + j); else b[j] = v[u]; } }
+    }
+}
+
+// LDS-DMA read: every wave owns a ring of R slots of 1 KiB in LDS; one global_load_lds_dwordx4 fills a slot; the wave
+// reads the slot back (ds_read_b128) once it has landed and sums it.  AUX = 0 default policy, 2 = nt.
+template <int R, int AUX>
+__global__ void __launch_bounds__(256) k_read_ldsdma(const v4f *__restrict__ a, uint64_t n, float *out) {
+    __shared__ v4f ring[4][R][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t nw = (uint64_t)gridDim.x * 4, w = blockIdx.x * 4ull + wave;
+    const uint64_t pieces = n / 64;              // 1-KiB pieces
+    v4f s = {0, 0, 0, 0};
+    for (uint64_t p = w * R; p < pieces; p += nw * R) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint64_t q = p + r; if (q >= pieces) q = pieces - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a + q * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&ring[wave][r][0], 16, 0, AUX);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < R; r++) s += ring[wave][r][lane];
+    }
+    if (s.x + s.y + s.z + s.w == 1.2345e30f) *out = s.x;
+}
+
+int main(int argc, char **argv) {
+    const uint64_t bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 8ull) << 30, n = bytes / 16;
+    v4f *a, *b; float *out;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&out, 8));
+    CK(hipMemset(a, 0, bytes)); CK(hipMemset(b, 0, bytes));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, buffer %llu GiB\n", prop.gcnArchName, cus, (unsigned long long)(bytes >> 30));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char *name, int wgs, double gb, auto launch) {
+        float best = 1e30f, sum = 0;
+        for (int it = 0; it < 6; it++) {
+            hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; if (it) sum += ms;
+        }
+        printf("%-46s wgs %6d  best %8.3f ms %7.1f GB/s   mean %7.1f GB/s\n", name, wgs, best, gb / (best * 1e-3), gb / (sum / 5 * 1e-3));
+        fflush(stdout);
+    };
+    const double G = bytes / 1e9;
+    for (int k : {2, 4, 8, 16, 64}) {
+        int g = cus * k;
+        timeit("read  U=4 plain interleaved", g, G, [&] { k_read<4, false, false><<<g, 256>>>(a, n, out); });
+        timeit("read  U=4 nt    interleaved", g, G, [&] { k_read<4, true, false><<<g, 256>>>(a, n, out); });
+        timeit("read  U=8 plain interleaved", g, G, [&] { k_read<8, false, false><<<g, 256>>>(a, n, out); });
+        timeit("read  U=8 nt    interleaved", g, G, [&] { k_read<8, true, false><<<g, 256>>>(a, n, out); });
+        timeit("read  U=4 plain blocked", g, G, [&] { k_read<4, false, true><<<g, 256>>>(a, n, out); });
+        timeit("read  U=4 nt    blocked", g, G, [&] { k_read<4, true, true><<<g, 256>>>(a, n, out); });
+    }
+    for (int k : {2, 4, 8}) {
+        int g = cus * k;
+        timeit("read  LDS-DMA ring 4 default", g, G, [&] { k_read_ldsdma<4, 0><<<g, 256>>>(a, n, out); });
+        timeit("read  LDS-DMA ring 4 nt", g, G, [&] { k_read_ldsdma<4, 2><<<g, 256>>>(a, n, out); });
+        timeit("read  LDS-DMA ring 8 default", g, G, [&] { k_read_ldsdma<8, 0><<<g, 256>>>(a, n, out); });
+        timeit("read  LDS-DMA ring 8 nt", g, G, [&] { k_read_ldsdma<8, 2><<<g, 256>>>(a, n, out); });
+    }
+    for (int k : {2, 4, 8, 16, 64}) {
+        int g = cus * k;
+        timeit("write U=4 plain", g, G, [&] { k_write<4, false><<<g, 256>>>(a, n); });
+        timeit("write U=4 nt", g, G, [&] { k_write<4, true><<<g, 256>>>(a, n); });
+    }
+    for (int k : {2, 4, 8, 16, 64}) {
+        int g = cus * k;
+        timeit("copy  U=4 plain/plain (r+w bytes)", g, 2 * G, [&] { k_copy<4, false, false><<<g, 256>>>(a, b, n); });
+        timeit("copy  U=4 nt/plain", g, 2 * G, [&] { k_copy<4, true, false><<<g, 256>>>(a, b, n); });
+        timeit("copy  U=4 plain/nt", g, 2 * G, [&] { k_copy<4, false, true><<<g, 256>>>(a, b, n); });
+        timeit("copy  U=4 nt/nt", g, 2 * G, [&] { k_copy<4, true, true><<<g, 256>>>(a, b, n); });
+        timeit("copy  U=8 nt/nt", g, 2 * G, [&] { k_copy<8, true, true><<<g, 256>>>(a, b, n); });
+    }
+    // hipMemcpy D2D as the runtime's own copy
+    timeit("hipMemcpyAsync D2D (r+w bytes)", 0, 2 * G, [&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
+    return 0;
+}
