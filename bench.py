@@ -183,6 +183,8 @@ def main():
     barrier()
     t_ingress = time.perf_counter() - t_in0
 
+    phase_ms = []   # per timed run: mean [phase 1, phase 2] ms of the SpMV, when GRAPHTAP_PB_PHASE_TIMING=1
+
     def timed_run(VR):
         """W untimed warm-up steps, a fresh initialize(V) (untimed), then ONE execute(K) -- so that the timed steps are
         exactly the reference's `pr <file> <n> K` (its TCSC_CF `last iteration` rule fires once, at step K) and the
@@ -194,11 +196,15 @@ def main():
         _lib.check(L.gt_program_enable_timing(h, 1))
         ms0, n0 = C.c_double(), C.c_uint32()
         _lib.check(L.gt_program_timing(h, C.byref(ms0), C.byref(n0), 1))
+        p1, p2, pn = C.c_double(), C.c_double(), C.c_uint32()
+        _lib.check(L.gt_graph_phase_times(G._h, C.byref(p1), C.byref(p2), C.byref(pn), 1))   # diagnostics (GRAPHTAP_PB_PHASE_TIMING=1): drop the warm-up's samples
         barrier()
         t0 = time.perf_counter()
         VR.execute(args.steps)
         barrier()
         dt = time.perf_counter() - t0
+        _lib.check(L.gt_graph_phase_times(G._h, C.byref(p1), C.byref(p2), C.byref(pn), 1))
+        phase_ms.append([p1.value, p2.value] if pn.value else None)
         if not G.exchange or VR.stats is not None and world > 1 and args.driver == "native" and args.backend == "nccl":
             spmv_ms, launches = VR.stats.spmv_ms, VR.stats.spmv_launches
         else:
@@ -254,7 +260,7 @@ def main():
         dt2, kms2, _ = timed_run(VR)
         f64_rec = {"spmv": "pb", "value": nnz * args.steps / dt2 / 1e9, "unit": "GTEPS", "ms_per_step": dt2 * 1e3 / args.steps, "kernel_ms": kms2,
                    "algorithmic_bytes_spmv": float(b_spmv_of("pb")), "frac": b_spmv_of("pb") / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                   "value_checksum": VR.checksum(out=None)[0]}
+                   "value_checksum": VR.checksum(out=None)[0], **({"phase_ms": phase_ms[1]} if len(phase_ms) > 1 and phase_ms[1] else {})}
 
     # streaming-copy ceiling of THIS box, measured live (4.7-4.8 TB/s copy against the 8 TB/s spec)
     ceiling = None
@@ -286,7 +292,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
                      "frac_with_apply": (b_spmv + b_fused) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "algorithmic_bytes_fused_apply": float(b_fused), "fused_apply_rows": fused_rows,
-                     "measured_ceiling_GBps": ceiling, "kernel_ms": kernel_ms, "launches": launches},
+                     "measured_ceiling_GBps": ceiling, "kernel_ms": kernel_ms, "launches": launches,
+                     **({"phase_ms": phase_ms[0]} if phase_ms and phase_ms[0] else {})},
     }
     if f64_rec is not None:
         out["f64_messages"] = f64_rec

@@ -479,17 +479,20 @@ template <> struct Msg<double, double> { static __device__ __forceinline__ doubl
 template <> struct Msg<double, float> { static __device__ __forceinline__ float val(float x, uint32_t) { return x; } };
 template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ uint32_t val(uint32_t x, uint32_t w) { return x == GT_INF ? GT_INF : x + w; } };
 
-// Loads of the once-read streams (LCOL, WT, group records in phase 1; VAL, LROW in phase 2) and stores of the once-written
-// value stream: NON-TEMPORAL. tools/hbm_ceiling2.hip on this pool: a read stream of contiguous per-workgroup spans runs at
-// 6.1 TB/s with default-policy loads and at 7.1-7.2 TB/s with nt loads (LDS-DMA nt: 7.0-7.3); writes 5.4-5.8 either way.
+// Cache policy of the streams. tools/hbm_ceiling2.hip on this pool: a pure read stream runs at 6.1 TB/s with default-policy
+// loads and at 7.1-7.2 TB/s with non-temporal ones (LDS-DMA nt: 7.0-7.3); writes 5.4-5.8 TB/s either way, copies 5.0-5.4.
+// In the kernels (A/B on one box, three rounds, profiles/r03/ab_nt.txt): nt loads of VAL / LROW make phase 2 ~8 % faster
+// (0.67-0.72 -> 0.60-0.66 ms); nt loads of LCOL / WT / group records change nothing in phase 1 (0.94-1.0 ms both ways); nt
+// STORES of the value stream cost phase 1 20 % (0.95 -> 1.19 ms) for 5 % in phase 2. Hence 2.
 #ifndef GT_PB_NT
-#define GT_PB_NT 1
+#define GT_PB_NT 2   // bit 0: loads of phase 1, bit 1: loads of phase 2, bit 2: stores of the value stream (A/B below)
 #endif
+constexpr bool NT_P1 = (GT_PB_NT & 1) != 0, NT_P2 = (GT_PB_NT & 2) != 0, NT_ST = (GT_PB_NT & 4) != 0;
 typedef uint32_t gt_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t gt_u32x4 __attribute__((ext_vector_type(4)));
-template <class S> __device__ __forceinline__ S ld_stream(const S *__restrict__ p) {
-#if GT_PB_NT
-    if constexpr (sizeof(S) == 4) { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); return __builtin_bit_cast(S, v); }
+template <bool NT, class S> __device__ __forceinline__ S ld_stream(const S *__restrict__ p) {
+    if constexpr (!NT) return *p;
+    else if constexpr (sizeof(S) == 4) { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); return __builtin_bit_cast(S, v); }
     else if constexpr (sizeof(S) == 8) { const gt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x2 *>(p)); return __builtin_bit_cast(S, v); }
     else if constexpr (sizeof(S) == 16) { const gt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p)); return __builtin_bit_cast(S, v); }
     else {
@@ -498,13 +501,10 @@ template <class S> __device__ __forceinline__ S ld_stream(const S *__restrict__ 
         v.a = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p)); v.b = __builtin_nontemporal_load(reinterpret_cast<const gt_u32x4 *>(p) + 1);
         return __builtin_bit_cast(S, v);
     }
-#else
-    return *p;
-#endif
 }
 template <class S> __device__ __forceinline__ void st_stream(S *__restrict__ p, const S &x) {
-#if GT_PB_NT >= 2
-    if constexpr (sizeof(S) == 4) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, x), reinterpret_cast<uint32_t *>(p));
+    if constexpr (!NT_ST) *p = x;
+    else if constexpr (sizeof(S) == 4) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, x), reinterpret_cast<uint32_t *>(p));
     else if constexpr (sizeof(S) == 8) __builtin_nontemporal_store(__builtin_bit_cast(gt_u32x2, x), reinterpret_cast<gt_u32x2 *>(p));
     else if constexpr (sizeof(S) == 16) __builtin_nontemporal_store(__builtin_bit_cast(gt_u32x4, x), reinterpret_cast<gt_u32x4 *>(p));
     else {
@@ -513,9 +513,6 @@ template <class S> __device__ __forceinline__ void st_stream(S *__restrict__ p, 
         const P2 v = __builtin_bit_cast(P2, x);
         __builtin_nontemporal_store(v.a, reinterpret_cast<gt_u32x4 *>(p)); __builtin_nontemporal_store(v.b, reinterpret_cast<gt_u32x4 *>(p) + 1);
     }
-#else
-    *p = x;
-#endif
 }
 
 template <class TV> struct alignas(sizeof(TV) * 4 > 16 ? 16 : sizeof(TV) * 4) V4 { TV a[4]; };
@@ -675,9 +672,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         for (int u = 0; u < U; u++) {
             const uint32_t g = (g0 + u < gend) ? g0 + u : gend - 1;
             const uint32_t q = g * 64 + lane;
-            olc[u] = ld_stream(LCOL4 + q);                        // 8 B/lane
-            ogw[u] = ld_stream(Gw + ((uint64_t)g * 8 + (lane & 7)));   // lane i holds dword i & 7 of the 32-byte group record
-            if constexpr (WEIGHTED) ow[u] = ld_stream(WT4 + q); else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
+            olc[u] = ld_stream<NT_P1>(LCOL4 + q);                        // 8 B/lane
+            ogw[u] = ld_stream<NT_P1>(Gw + ((uint64_t)g * 8 + (lane & 7)));   // lane i holds dword i & 7 of the 32-byte group record
+            if constexpr (WEIGHTED) ow[u] = ld_stream<NT_P1>(WT4 + q); else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
         }
     };
     uint32_t g0 = (q0c >> 6) + wave * U;
@@ -773,14 +770,14 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     for (; q + (P2_U - 1) * P2_THREADS < qb; q += P2_U * P2_THREADS) {
         C4 r[P2_U]; V4<TV> a[P2_U];
 #pragma unroll
-        for (int u = 0; u < P2_U; u++) { r[u] = ld_stream(LROW4 + (q + u * P2_THREADS)); a[u] = ld_stream(VAL4 + (q + u * P2_THREADS)); }
+        for (int u = 0; u < P2_U; u++) { r[u] = ld_stream<NT_P2>(LROW4 + (q + u * P2_THREADS)); a[u] = ld_stream<NT_P2>(VAL4 + (q + u * P2_THREADS)); }
 #pragma unroll
         for (int u = 0; u < P2_U; u++)
 #pragma unroll
             for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r[u].c[j], (T)a[u].a[j]);
     }
     for (; q < qb; q += P2_THREADS) {
-        const C4 r0 = ld_stream(LROW4 + q); const V4<TV> a0 = ld_stream(VAL4 + q);
+        const C4 r0 = ld_stream<NT_P2>(LROW4 + q); const V4<TV> a0 = ld_stream<NT_P2>(VAL4 + q);
 #pragma unroll
         for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
     }
@@ -871,6 +868,9 @@ struct gt_pb {
     void *VAL = nullptr;       // value stream scratch, 8 B/entry once an f64 SpMV ran, else 4 B/entry
     uint32_t val_bytes = 0;
     uint32_t val_cap = 0;      // bytes per slot VAL was allocated for (gt_pb_reserve_val)
+    // GRAPHTAP_PB_PHASE_TIMING=1: HIP events around phase 1 and phase 2 of every whole SpMV (gt_graph_phase_times)
+    std::vector<hipEvent_t> pt_ev;   // triples: before phase 1, between, after phase 2
+    size_t pt_used = 0;
     uint32_t val_allocs = 0;   // allocations of VAL so far (gt_exec_stats.allocs_in_execute counts those made inside execute())
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice (and kind), largest chunk first
@@ -888,6 +888,7 @@ void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
     void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single, pb->split_bins};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : pb->pt_ev) (void)hipEventDestroy(e);
     delete pb;
 }
 
@@ -1278,6 +1279,12 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             pb->val_min = IS_MIN ? 1 : 0;
         }
     }
+    static const bool phase_timing = getenv("GRAPHTAP_PB_PHASE_TIMING") != nullptr;
+    const bool pt = phase_timing && phases == (GT_PB_PREPARE | GT_PB_PHASE1 | GT_PB_PHASE2);
+    if (pt) {
+        while (pb->pt_ev.size() < pb->pt_used + 3) { hipEvent_t e; GT_HIP(hipEventCreate(&e)); pb->pt_ev.push_back(e); }
+        GT_HIP(hipEventRecord(pb->pt_ev[pb->pt_used], s));
+    }
     if (phases & GT_PB_PHASE1) {
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
         auto scatter = [&](uint32_t c0, uint32_t c1) {
@@ -1291,6 +1298,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         if (g->info.x_slices == 1) scatter(pb->bound[0], skip_source ? pb->bound[2] : pb->bound[4]);
         else scatter(pb->slice_chunk[slice_lo], pb->slice_chunk[slice_hi]);   // exchange layout: identity x, every window dense
     }
+    if (pt) GT_HIP(hipEventRecord(pb->pt_ev[pb->pt_used + 1], s));
     if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
         const uint32_t *ap = filter ? pb->active_prefix : nullptr;
@@ -1305,7 +1313,25 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             k_pb_gather<T, TV, IS_MIN, 0><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
         }
     }
+    if (pt) { GT_HIP(hipEventRecord(pb->pt_ev[pb->pt_used + 2], s)); pb->pt_used += 3; }
     GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+
+// mean duration of phase 1 / phase 2 over the SpMVs recorded since the last reset (GRAPHTAP_PB_PHASE_TIMING=1)
+extern "C" int gt_graph_phase_times(gt_graph *g, double *phase1_ms, double *phase2_ms, uint32_t *spmvs, int reset) {
+    GT_REQUIRE(g && phase1_ms && phase2_ms && spmvs, GT_ERR_INVALID, "null argument");
+    *phase1_ms = *phase2_ms = 0; *spmvs = 0;
+    gt_pb *pb = g->pb;
+    if (!pb) return GT_OK;
+    GT_HIP(hipDeviceSynchronize());
+    for (size_t i = 0; i + 2 < pb->pt_used; i += 3) {
+        float a = 0, b = 0;
+        GT_HIP(hipEventElapsedTime(&a, pb->pt_ev[i], pb->pt_ev[i + 1])); GT_HIP(hipEventElapsedTime(&b, pb->pt_ev[i + 1], pb->pt_ev[i + 2]));
+        *phase1_ms += a; *phase2_ms += b; (*spmvs)++;
+    }
+    if (*spmvs) { *phase1_ms /= *spmvs; *phase2_ms /= *spmvs; }
+    if (reset) pb->pt_used = 0;
     return GT_OK;
 }
 

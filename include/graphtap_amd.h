@@ -228,6 +228,9 @@ int gt_graph_exchange_plan(const gt_graph *g, gt_exchange_plan *plan);
  * same for every rank count. */
 int gt_graph_vertex_ids(const gt_graph *g, uint32_t *host_out, uint64_t count);
 /* Graph::free (mat/graph.hpp:76-81). Programs borrow the graph: free them first. */
+/* Diagnostics: with GRAPHTAP_PB_PHASE_TIMING=1 in the environment every whole propagation-blocking SpMV records HIP events
+ * around its two phases; this returns their mean durations since the last reset (zeros when nothing was recorded). */
+int gt_graph_phase_times(gt_graph *g, double *phase1_ms, double *phase2_ms, uint32_t *spmvs, int reset);
 int gt_graph_free(gt_graph *g);
 
 /* ---- programs: replaces Vertex_Program<> ------------------------------ */
