@@ -92,7 +92,7 @@ def cpu_baseline_reference(e, scale, seed, iters=20, nproc=8):
         try:
             t0 = time.perf_counter()
             r = subprocess.run([mpirun, "-np", str(nproc), exe, path, str(1 << scale), str(iters)], env=env,
-                               capture_output=True, text=True, timeout=150)
+                               capture_output=True, text=True, timeout=300)
             wall = time.perf_counter() - t0
         except Exception:
             return None
@@ -107,13 +107,33 @@ def cpu_baseline_reference(e, scale, seed, iters=20, nproc=8):
                       "Execute %.2f s, Ingress %s s, wall %.0f s, %s" % (nproc, len(e), scale, seed, iters, t, ing[-1] if ing else "?", wall, _cpu_model())}
 
 
+def _host_cores():
+    """Cores this process may use: the scheduler affinity, cut by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(scale, seed):
-    sample = min(16 << scale, 1 << 27)   # bounded sample: the first 2^27 records (1 GiB) of the same stream
+    """The reference on the box's host cores: as many MPI ranks as it has cores (the largest count <= 64 that the reference's
+    integer_factorize, src/mat/tiling.hpp:65-73, splits into a near-square rank grid), over a bounded sample of the same stream:
+    the first 2^28 records with 16+ cores, 2^27 below."""
+    cores = _host_cores()
+    nproc = max(n for n in (1, 2, 4, 6, 8, 9, 12, 16, 20, 24, 25, 30, 32, 36, 42, 48, 49, 56, 64) if n <= max(cores, 1))
+    sample = min(16 << scale, 1 << (28 if nproc >= 16 else 27))
     e = _sample_edges(scale, seed, sample)
     port = cpu_baseline_port(e[:min(sample, 1 << 26)], scale, seed)
-    ref = cpu_baseline_reference(e, scale, seed)
+    ref = cpu_baseline_reference(e, scale, seed, nproc=nproc)
+    if ref is None and nproc > 8:        # e.g. not enough memory for that many ranks: the 8-rank run of the earlier rounds
+        ref = cpu_baseline_reference(e[:1 << 27], scale, seed, nproc=8)
     if ref is None:
         return port, None
+    ref["host_cores"] = cores
     return ref, port
 
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "gt_program_initialize": (C.c_int, [_vp]),
     "gt_program_initialize_from": (C.c_int, [_vp, _vp]),
     "gt_graph_phase_times": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]),
+    "gt_program_prepare": (C.c_int, [_vp, C.c_uint32]),
     "gt_program_execute": (C.c_int, [_vp, C.c_uint32, C.POINTER(ExecStats)]),
     "gt_program_set_stream": (C.c_int, [_vp, _vp]),
     "gt_program_enable_timing": (C.c_int, [_vp, C.c_int]),

@@ -446,8 +446,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     GT_REQUIRE(gt_has_exchange(g), GT_ERR_STATE, "gt_dist_execute needs a graph built with the exchange layout (nranks > 1, or GRAPHTAP_FORCE_EXCHANGE)");
     GT_REQUIRE((int)g->info.nranks == d->nranks && (int)g->info.rank == d->rank, GT_ERR_INVALID,
                "graph is tile-row %u of %u, the communicator says rank %d of %d", g->info.rank, g->info.nranks, d->rank, d->nranks);
-    if (!p->initialized) { int st = gt_program_initialize(p); if (st != GT_OK) return st; }   // vp:410-411
-    if (iters == 0) p->check_sticky = true;                                                    // vp:412-413
+    { int st = gt_program_prepare(p, iters); if (st != GT_OK) return st; }   // vp:410-413 + the message width of this run
     const bool check = p->check_sticky;
     const bool col = (p->prm.order == GT_COL);
     const uint32_t K = g->info.x_slices;

@@ -519,8 +519,11 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
         case GT_DEG: p->semiring = GT_PLUS_U32; break;
         case GT_PR:
             p->semiring = GT_PLUS_F64; p->y_bytes = 8;
-            p->x_f32 = (g->spmv_variant == GT_SPMV_PB_F32MSG);
-            p->x_bytes = p->x_f32 ? 4 : 8;
+            // f32 messages (GT_SPMV_PB_F32MSG) are for fixed iteration counts; in converge mode the program switches to f64 ones
+            // (gt_program_prepare), so the buffers hold 8 bytes per element either way
+            p->f32_capable = (g->spmv_variant == GT_SPMV_PB_F32MSG);
+            p->x_f32 = p->f32_capable;
+            p->x_bytes = p->x_f32 ? 4 : 8; p->x_alloc_bytes = 8;
             break;
         case GT_SSSP: p->semiring = GT_MINPLUS_U32; break;
         default: p->semiring = GT_MIN_U32; break;
@@ -529,7 +532,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
     p->x_elems = g->x_len;
     p->y_elems = (prm->order == GT_COL) ? (uint64_t)g->info.nranks * g->info.seg_stride : g->info.nnzrows;
     bool ok = hipMalloc((void **)&p->s0, (uint64_t)H * 4) == hipSuccess && hipMalloc((void **)&p->C, H) == hipSuccess &&
-              hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_bytes) == hipSuccess &&
+              hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_alloc_bytes) == hipSuccess &&
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
@@ -552,8 +555,8 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
              hipMalloc((void **)&p->deg_c, nr * 4) == hipSuccess && hipMalloc((void **)&p->C_c, nr) == hipSuccess;
     }
     if (ok && gt_has_exchange(g))
-        ok = hipMalloc(&p->xseg, std::max<uint64_t>(g->info.nnzcols, 1) * p->x_bytes) == hipSuccess &&
-             hipMalloc(&p->send_own, std::max<uint64_t>(g->send_elems, 1) * p->x_bytes) == hipSuccess;
+        ok = hipMalloc(&p->xseg, std::max<uint64_t>(g->info.nnzcols, 1) * p->x_alloc_bytes) == hipSuccess &&
+             hipMalloc(&p->send_own, std::max<uint64_t>(g->send_elems, 1) * p->x_alloc_bytes) == hipSuccess;
     if (!ok) { gt_program_free(p); gt_set_error("out of device memory for program state"); return GT_ERR_HIP; }
     p->x = p->x_own; p->send = p->send_own;
     *out = p;
@@ -590,6 +593,7 @@ static int init_common(gt_program *p) {
     hipStream_t s = p->stream;
     static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
     p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter;
+    if (p->f32_capable && !p->x_f32) { p->x_f32 = true; p->x_bytes = 4; }   // back to the f32 messages a converge-mode run had left (gt_program_prepare)
     p->last_active = (p->prm.kind == GT_BFS || p->prm.kind == GT_SSSP) ? 1 : ~0ull;   // the root alone is active (bfs.h:37-50, sssp.h:33-42)
     switch (p->prm.kind) {
         case GT_DEG:  // deg.h:31-34
@@ -637,7 +641,7 @@ static int init_common(gt_program *p) {
         if (st != GT_OK) return st;
     }
     if (g->spmv_variant != GT_SPMV_EDGE && g->pb && p->prm.order == GT_ROW) {   // the value stream of the SpMV this program runs: not inside execute()
-        int st = gt_pb_reserve_val(g, (p->prm.kind == GT_PR && !p->x_f32) ? 8u : 4u, s);
+        int st = gt_pb_reserve_val(g, p->prm.kind == GT_PR ? 8u : 4u, s);   // PageRank: both message widths (converge mode runs f64 ones)
         if (st != GT_OK) return st;
     }
     { int st = gt_kernels_preload(s); if (st != GT_OK) return st; }
@@ -666,6 +670,31 @@ int gt_program_initialize_from(gt_program *p, const gt_program *other) {
         if (st != GT_OK) return st;
     }
     // non-stationary programs ignore `other` (vp:489-493)
+    return GT_OK;
+}
+
+// What every driver calls first in execute(iters) (vp:408-413): initialize() if nobody did, the sticky converge-mode flag, and --
+// PageRank under GT_SPMV_PB_F32MSG -- the message width of the run. With f32 messages the iteration at which the last row
+// stops "changing" depends on rounding noise (a hub's rank of ~1e4 carries ~1e-4 of it, above the reference's absolute
+// tolerance 1e-5, pr.h:13), i.e. on the order a layout adds in; the reference's count is deterministic. So converge mode runs
+// f64 messages (exactly the GT_SPMV_PB arithmetic), fixed counts keep the f32 ones. Call BEFORE asking for the x / send buffers.
+int gt_program_prepare(gt_program *p, uint32_t iters) {
+    GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
+    if (!p->initialized) { int st = init_common(p); if (st != GT_OK) return st; }   // vp:410-411
+    if (iters == 0) p->check_sticky = true;                                         // vp:412-413 (never reset by the reference)
+    if (p->prm.kind == GT_PR && p->f32_capable) {
+        const bool want_f32 = !p->check_sticky;
+        if (want_f32 != p->x_f32) {
+            GT_REQUIRE(p->x == p->x_own && p->send == p->send_own, GT_ERR_STATE, "the message width changes with the mode of the run: restore the program's own x / send buffers first");
+            p->x_f32 = want_f32; p->x_bytes = want_f32 ? 4 : 8; p->x_fresh = false;   // messages are recomputed from the ranks in the new width
+            hipStream_t s = p->stream;
+            GT_HIP(hipMemsetAsync(p->x_own, 0, std::max<uint64_t>(p->x_elems, 1) * p->x_alloc_bytes, s));   // 0 is the neutral message in both widths
+            if (p->xseg) {
+                GT_HIP(hipMemsetAsync(p->xseg, 0, std::max<uint64_t>(p->g->info.nnzcols, 1) * p->x_alloc_bytes, s));
+                GT_HIP(hipMemsetAsync(p->send_own, 0, std::max<uint64_t>(p->g->send_elems, 1) * p->x_alloc_bytes, s));
+            }
+        }
+    }
     return GT_OK;
 }
 
@@ -819,7 +848,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
             if (!last) p->cf_filtered++;
             st = gt_tcsc_cf_spmv(const_cast<gt_graph *>(g), (const double *)p->x, (double *)p->y, p->iteration == 0, true, last, s);
         } else {
-            st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source);
+            st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source, p->f32_capable && !p->x_f32);
         }
         if (st != GT_OK) return st;
         p->fused = fuse;
@@ -842,7 +871,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         }
     }
     if (lo == 0) {
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, 0, 0, GT_PB_PREPARE);
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, 0, 0, GT_PB_PREPARE, nullptr, false, p->f32_capable && !p->x_f32);
         if (st != GT_OK) return st;
         if (timed) { hipEvent_t e0; st = timing_event(&e0); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e0, s)); }
     }
@@ -850,7 +879,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         hipStream_t hs = p->slice_streams[k % p->slice_streams.size()];
         GT_HIP(hipEventRecord(p->slice_in[k], s));
         GT_HIP(hipStreamWaitEvent(hs, p->slice_in[k], 0));
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, hs, p->x_f32, p, p->init_epoch, k, k + 1, GT_PB_PHASE1);
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, hs, p->x_f32, p, p->init_epoch, k, k + 1, GT_PB_PHASE1, nullptr, false, p->f32_capable && !p->x_f32);
         if (st != GT_OK) return st;
         GT_HIP(hipEventRecord(p->slice_done[k], hs));
     }
@@ -859,7 +888,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         gt_pr_epilogue epi{};
         const bool fuse = fused_epilogue(p, &epi);
         if (fuse && p->fuse_count) GT_HIP(hipMemsetAsync(p->d_active, 0, sizeof(unsigned long long), s));
-        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2, fuse ? &epi : nullptr);
+        int st = gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2, fuse ? &epi : nullptr, false, p->f32_capable && !p->x_f32);
         if (st != GT_OK) return st;
         p->fused = fuse;
         if (timed) { hipEvent_t e1; st = timing_event(&e1); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e1, s)); p->spmv_done++; }
@@ -1006,8 +1035,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     GT_REQUIRE(p, GT_ERR_INVALID, "null argument");
     GT_REQUIRE(!gt_has_exchange(p->g), GT_ERR_STATE,
                "gt_program_execute runs single-rank graphs; multi-rank runs drive scatter_gather/combine/apply with an exchange of x between them");
-    if (!p->initialized) { int st = init_common(p); if (st != GT_OK) return st; }  // vp:410-411
-    if (iters == 0) p->check_sticky = true;                                        // vp:412-413 (never reset by the reference)
+    { int st = gt_program_prepare(p, iters); if (st != GT_OK) return st; }   // vp:410-413 + the message width of this run
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->spmspv_allocs = 0;

@@ -136,6 +136,8 @@ struct gt_program {
     uint32_t spmv_done = 0;     // complete SpMVs among the timed event pairs (a sliced SpMV records one pair per slice)
     uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
     bool x_f32 = false;         // PageRank under GT_SPMV_PB_F32MSG: the message vector itself is f32 (halves the exchange)
+    bool f32_capable = false;   // ... which holds for fixed iteration counts; converge mode switches to f64 messages (gt_program_prepare)
+    uint32_t x_alloc_bytes = 4; // bytes per element the message buffers were allocated for
     // sliced combine (several ranks): phase 1 of slice k runs on helper stream k % size so that the tail of one slice
     // overlaps the start of the next (and, in the pipelined driver, the exchange of the later slices)
     // gt_program_execute: PageRank's apply of this iteration is fused into phase 2 for the row bins one workgroup owns
@@ -254,4 +256,4 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
                    const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu,
-                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr, bool skip_source = false);
+                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr, bool skip_source = false, bool f64_messages = false);

@@ -74,6 +74,8 @@ def run(engine, iters, group=None):
     if iters == 0:
         engine.check_sticky = True      # vp:412-413: check_for_convergence is never cleared once execute(0) ran
     check = getattr(engine, "check_sticky", False)
+    if hasattr(engine, "prepare"):
+        engine.prepare(iters)           # gt_program_prepare: before the buffers are looked at (it fixes their element width)
     p = engine.nranks
     K = getattr(engine, "x_slices", 1)
     x = engine.x_tensor()               # the message vector the local SpMV reads

@@ -74,6 +74,27 @@ class _HipEngine:
         check(setter(self.prog._h, C.c_void_p(t.data_ptr())))
         return t
 
+    def prepare(self, iters):
+        """gt_program_prepare: the first call of an execute(iters). It may change the element width of the message buffers
+        (PageRank with f32 messages runs f64 ones in converge mode): tensors installed for the other width are taken back."""
+        def width():
+            w = C.c_uint32()
+            check(lib().gt_program_x(self.prog._h, None, None, C.byref(w)))
+            return w.value
+        before = width()
+        if self._x is not None and self.prog.G.exchange:
+            check(lib().gt_program_set_x(self.prog._h, None))
+        if self._send is not None:
+            check(lib().gt_program_set_send(self.prog._h, None))
+        check(lib().gt_program_prepare(self.prog._h, iters))
+        if width() != before:
+            self._x = self._send = None
+        else:   # same width: the installed tensors stay
+            if self._x is not None and self.prog.G.exchange:
+                check(lib().gt_program_set_x(self.prog._h, C.c_void_p(self._x.data_ptr())))
+            if self._send is not None and self._send.numel():
+                check(lib().gt_program_set_send(self.prog._h, C.c_void_p(self._send.data_ptr())))
+
     def x_tensor(self):
         """The message vector the local SpMV reads (receive side of the exchange on several ranks); the
         single-rank case views the engine's own buffer."""

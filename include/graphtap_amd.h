@@ -264,6 +264,13 @@ int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int re
  * One rank, BFS on a symmetric graph: an iteration that is likely to run bottom-up (it reads vertex states, not messages)
  * does not write x in scatter_gather -- combine does if it takes the push sweep after all; GRAPHTAP_BFS_BOTTOM_UP=0 for
  * callers that want x after every scatter_gather. */
+/* First call of every execute(iters) (Vertex_Program::execute, vp:408-413): initializes the program if nobody did, makes
+ * converge mode sticky for iters == 0, and fixes the message width of the run. PageRank on a GT_SPMV_PB_F32MSG graph keeps f32
+ * messages for fixed iteration counts and switches to f64 ones in converge mode, where the reference's iteration count has to
+ * be met on every layout (f32 rounding noise of a hub's rank exceeds pr.h:13's absolute tolerance). gt_program_execute and
+ * gt_dist_execute call it themselves; phase-level drivers call it BEFORE gt_program_x / gt_program_send, whose element
+ * width it may change (installed caller buffers must be taken back first: gt_program_set_x(p, NULL)). */
+int gt_program_prepare(gt_program *p, uint32_t iters);
 int gt_program_x(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);
 int gt_program_set_x(gt_program *p, void *dev_ptr);
 int gt_program_send(gt_program *p, void **dev_ptr, uint64_t *elems, uint32_t *elem_bytes);

@@ -283,6 +283,31 @@ def test_pagerank_converge_mode_matches_reference(gt, name, known_answers):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_pagerank_converge_mode_is_deterministic_with_f32_messages(gt, name, known_answers, monkeypatch):
+    """The benched variant (pb_f32msg) in converge mode: the reference's iteration count and ranks on both layouts (hubs-first
+    and -- GRAPHTAP_FORCE_EXCHANGE -- the exchange layout), because converge mode runs f64 messages (gt_program_prepare;
+    apps/pr.h:43-47, vp:1885-1923); a fixed-count run after it on the same program is back to f32 messages."""
+    c = load_case(name); n = c["num_vertices"] + 1
+    monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    for cf, key in ((False, "np1_prconv_tcsc"), (True, "np1_prconv_cf")):
+        r = run_pr(gt, c["edges"], c["num_vertices"], 0, cf)
+        assert r["iterations"] == known_answers[name][key]["iterations"]
+        ref = c[key + "_c"]
+        assert (np.abs(r["rank"][:n] - ref) / ref).max() < PR_RTOL
+    # one program: execute(20) [f32 messages], initialize, execute() [f64 messages], initialize, execute(20) again
+    G = gt.Graph(); G.load_edges(c["edges"], c["num_vertices"], c["num_vertices"], True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    P = gt.PR_Program(G, True, False, False, gt._ROW_)
+    P.initialize(V); P.execute(20); a = P.V["rank"].copy()
+    P.initialize(V); P.execute(); assert P.iteration == known_answers[name]["np1_prconv_cf"]["iterations"]
+    assert (np.abs(P.V["rank"][:n] - c["np1_prconv_cf_c"]) / c["np1_prconv_cf_c"]).max() < PR_RTOL
+    P.initialize(V); P.execute(20); b = P.V["rank"]
+    assert (np.abs(a[:n] - b[:n]) / b[:n]).max() < 1e-12   # same arithmetic (the LDS atomics' order is free)
+    assert (np.abs(b[:n] - c["np1_pr20_c"]) / c["np1_pr20_c"]).max() < PR_RTOL
+    P.free(); V.free(); G.free()
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_bfs_sssp_cc_bit_exact(gt, name, known_answers):
     c = load_case(name); nv = c["num_vertices"]; n = nv + 1
     roots = [(c["root"], "")] + ([(0, "0")] if c["root"] != 0 and "np1_bfs0_a" in c else [])

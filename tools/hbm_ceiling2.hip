@@ -93,6 +93,27 @@ __global__ void __launch_bounds__(256) k_read_ldsdma(const v4f *__restrict__ a, 
     if (s.x + s.y + s.z + s.w == 1.2345e30f) *out = s.x;
 }
 
+
+// mixed traffic shaped like the SpMV phases: every workgroup owns a span of the input and a span of the output and moves NR
+// 16-byte loads per NW 16-byte stores (phase 1 of R-MAT-26: 2.55 GB in / 1.63 GB out ~ 3 : 2; phase 2: 2.77 / 0.38 ~ 7 : 1)
+template <int NR, int NW, bool NT>
+__global__ void __launch_bounds__(256) k_mix(const v4f *__restrict__ a, v4f *__restrict__ b, uint64_t n_in) {
+    const uint64_t per = (n_in / gridDim.x / (256 * NR)) * (256 * NR);
+    const v4f *src = a + blockIdx.x * per;
+    v4f *dst = b + blockIdx.x * (per / NR * NW);
+    for (uint64_t k = 0; k * 256 * NR < per; k++) {
+        const uint64_t i = k * 256 * NR + threadIdx.x;
+        v4f v[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) v[u] = NT ? __builtin_nontemporal_load(src + i + u * 256) : src[i + u * 256];
+        v4f s = v[0];
+#pragma unroll
+        for (int u = 1; u < NR; u++) s += v[u];
+#pragma unroll
+        for (int u = 0; u < NW; u++) dst[(k * NW + u) * 256 + threadIdx.x] = s;
+    }
+}
+
 int main(int argc, char **argv) {
     const uint64_t bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 8ull) << 30, n = bytes / 16;
     v4f *a, *b; float *out;
@@ -140,6 +161,14 @@ int main(int argc, char **argv) {
         timeit("copy  U=4 plain/nt", g, 2 * G, [&] { k_copy<4, false, true><<<g, 256>>>(a, b, n); });
         timeit("copy  U=4 nt/nt", g, 2 * G, [&] { k_copy<4, true, true><<<g, 256>>>(a, b, n); });
         timeit("copy  U=8 nt/nt", g, 2 * G, [&] { k_copy<8, true, true><<<g, 256>>>(a, b, n); });
+    }
+    for (int k : {2, 4, 8, 32}) {
+        int g = cus * k;
+        const uint64_t per3 = (n / g / (256 * 3)) * (256 * 3), per7 = (n / g / (256 * 7)) * (256 * 7);
+        timeit("mix 3 reads : 2 writes plain (r+w bytes)", g, per3 * g * 16.0 * (1 + 2.0 / 3) / 1e9, [&] { k_mix<3, 2, false><<<g, 256>>>(a, b, n); });
+        timeit("mix 3 reads : 2 writes nt loads", g, per3 * g * 16.0 * (1 + 2.0 / 3) / 1e9, [&] { k_mix<3, 2, true><<<g, 256>>>(a, b, n); });
+        timeit("mix 7 reads : 1 write  plain", g, per7 * g * 16.0 * (1 + 1.0 / 7) / 1e9, [&] { k_mix<7, 1, false><<<g, 256>>>(a, b, n); });
+        timeit("mix 7 reads : 1 write  nt loads", g, per7 * g * 16.0 * (1 + 1.0 / 7) / 1e9, [&] { k_mix<7, 1, true><<<g, 256>>>(a, b, n); });
     }
     // hipMemcpy D2D as the runtime's own copy
     timeit("hipMemcpyAsync D2D (r+w bytes)", 0, 2 * G, [&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
