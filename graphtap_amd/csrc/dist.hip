@@ -15,6 +15,7 @@
 // on one GPU, one host thread each, exchanging with device copies -- the p-rank rehearsal a one-GPU box allows (RCCL refuses
 // two ranks on one device), used by tests/.
 #include <dlfcn.h>
+#include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -22,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -41,6 +43,7 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;   // optional (diagnostics)
 };
 Rccl *rccl() {
     static Rccl r;
@@ -58,7 +61,7 @@ Rccl *rccl() {
 #define GT_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
         GT_SYM(GetUniqueId, "ncclGetUniqueId"); GT_SYM(CommInitRank, "ncclCommInitRank"); GT_SYM(CommDestroy, "ncclCommDestroy");
         GT_SYM(GroupStart, "ncclGroupStart"); GT_SYM(GroupEnd, "ncclGroupEnd"); GT_SYM(Send, "ncclSend"); GT_SYM(Recv, "ncclRecv");
-        GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GetErrorString, "ncclGetErrorString");
+        GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GetErrorString, "ncclGetErrorString"); GT_SYM(CommCount, "ncclCommCount");
 #undef GT_SYM
         if (!(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce && r.GetErrorString)) r.lib = nullptr;
     });
@@ -114,9 +117,77 @@ __global__ void k_scatter_pairs(const uint2 *__restrict__ pairs, uint32_t n, uin
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint2 pv = pairs[i]; xblock[pv.x] = pv.y; }
 }
 
+// one launch for all the blocks of x that arrive as pairs: they start from infinity() (blockIdx.y = block)
+__global__ void k_fill_blocks(uint32_t *__restrict__ x, const BlockTab *__restrict__ rtab, const uint8_t *__restrict__ sel, uint32_t v) {
+    const uint32_t b = blockIdx.y;
+    if (!sel[b]) return;
+    const BlockTab t = rtab[b];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < t.len; i += gridDim.x * blockDim.x) x[t.start + i] = v;
+}
+// ---- frontier lists on several ranks (the reference's (xi, xv) pairs at any np, vp:711-784, 970-1013, 1475-1489)
+// send positions of every owned column: inverse of send_idx as a CSR (built once per graph)
+__global__ void k_send_keys(const uint32_t *__restrict__ send_idx, uint32_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ pos) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { key[i] = send_idx[i]; pos[i] = i; }
+}
+__global__ void k_send_ptr(const uint32_t *__restrict__ key_sorted, uint32_t n, uint32_t ncols, uint32_t *__restrict__ ptr) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= ncols; c += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n;   // first i with key_sorted[i] >= c
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (key_sorted[mid] < c) lo = mid + 1; else hi = mid; }
+        ptr[c] = lo;
+    }
+}
+// the vertices the last apply changed -> (index in block, message) pairs in every block of the send buffer that carries their
+// column. A list longer than `cap` (or none: n_dev's top bit) raises *flag instead: the rank then sends dense blocks.
+__global__ void k_pairs_from_list(const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_dev, uint32_t cap, const uint8_t *__restrict__ IJ,
+                                  const uint32_t *__restrict__ JV, const uint32_t *__restrict__ send_ptr, const uint32_t *__restrict__ send_pos,
+                                  const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm, int kind, const BlockTab *__restrict__ stab, uint32_t nb,
+                                  uint32_t *__restrict__ cursor, uint2 *__restrict__ pairs, uint32_t *__restrict__ flag) {
+    const uint32_t n = *n_dev;
+    if (n > cap) { if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 1u; return; }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = list[i];
+        if (!(IJ[v] & 2u)) continue;   // no column: the vertex sends nothing
+        const uint32_t c = JV[v];
+        const uint32_t m = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+        for (uint32_t j = send_ptr[c], j1 = send_ptr[c + 1]; j < j1; j++) {
+            const uint32_t pos = send_pos[j], b = block_of(stab, nb, pos);
+            pairs[stab[b].start + atomicAdd(&cursor[b], 1u)] = uint2{pos - stab[b].start, m};
+        }
+    }
+}
+// the words of the per-iteration all-reduce: [0] active vertices, [1] ranks that need a second (dense) round, then for every
+// (source rank, block) the number of active messages, bit 32 set when the block travels as pairs
+__global__ void k_words(unsigned long long *__restrict__ w, uint32_t nwords, const unsigned long long *__restrict__ d_active, const uint32_t *__restrict__ flag,
+                        const uint32_t *__restrict__ counts, const uint8_t *__restrict__ pair_form, uint32_t me, uint32_t nb) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) {
+        unsigned long long v = 0;
+        if (i == 0) v = d_active ? *d_active : 0ull;
+        else if (i == 1) v = (flag && *flag) ? 1ull : 0ull;
+        else if (i >= 2 + me * nb && i < 2 + (me + 1) * nb) {
+            const uint32_t b = i - 2 - me * nb;
+            const bool pf = pair_form ? pair_form[b] != 0 : !(flag && *flag);   // list mode: every block as pairs
+            v = (unsigned long long)counts[b] | (pf ? (1ull << 32) : 0ull);
+        }
+        w[i] = v;
+    }
+}
+// the received pairs of all blocks -> one frontier: local column, message, entry count (ftab[b] = {first pair's output slot, pairs})
+struct FrontTab { uint32_t out0, n; };
+__global__ void k_pairs_frontier(const uint2 *__restrict__ pairs, const BlockTab *__restrict__ rtab, const FrontTab *__restrict__ ftab, uint32_t nb, uint32_t total,
+                                 const uint32_t *__restrict__ JA, uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nb;   // last block whose out0 <= i among those that hold pairs (empty ones share their successor's out0)
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (ftab[mid].out0 <= i) lo = mid; else hi = mid; }
+        while (ftab[lo].n == 0 || i - ftab[lo].out0 >= ftab[lo].n) lo--;   // step back over empty blocks with the same out0
+        const uint2 pv = pairs[rtab[lo].start + (i - ftab[lo].out0)];
+        const uint32_t c = rtab[lo].start + pv.x;
+        col[i] = c; val[i] = pv.y; deg[i] = JA[c + 1] - JA[c];
+    }
+}
+
 // ---- loopback: what the p ranks of one process share
 struct LoopPeer { const char *send = nullptr; const uint32_t *y = nullptr; const gt_graph *g = nullptr; uint32_t x_bytes = 0; uint64_t word = 0;
-                  const uint2 *pairs = nullptr; const uint32_t *counts = nullptr; /* host [K*P] active messages per send block, or null = all dense */ };
+                  const uint2 *pairs = nullptr; const unsigned long long *words = nullptr; const uint32_t *counts = nullptr; /* host [K*P] active messages per send block, or null = all dense */ };
 struct LoopCtx {
     int n = 0;
     std::mutex mu;
@@ -157,6 +228,23 @@ struct gt_dist {
     std::vector<BlockTab> stab, rtab;                // host copies: send blocks, blocks of x
     std::vector<uint32_t> cnt_send, cnt_recv;        // [K*P] this iteration: what I send / what each peer sends me
     bool sparse_now = false;                         // this iteration's exchange uses the counts above
+    bool lists_protocol = false;                     // the converge-mode loop of the min programs (counts ride the convergence all-reduce)
+    std::vector<uint8_t> form_send, form_recv;       // [K*P] 1 = the block travels as (index, value) pairs this iteration
+    // frontier lists on several ranks: send positions of every owned column (CSR), tables and words of the per-iteration all-reduce
+    uint32_t *send_ptr = nullptr, *send_pos = nullptr;
+    BlockTab *d_rtab = nullptr;                      // [K*P] blocks of x
+    FrontTab *d_ftab = nullptr;                      // [K*P] where the pairs of each block go in the frontier
+    std::vector<FrontTab> h_ftab;
+    uint8_t *d_rsel = nullptr;                       // [K*P] blocks of x to pre-fill with infinity()
+    uint32_t *d_flag = nullptr;                      // 1 = this rank's list did not fit: it needs the dense round
+    unsigned long long *d_words = nullptr; uint32_t nwords = 0;   // [2 + P*K*P]
+    std::vector<unsigned long long> h_words;
+    uint32_t list_send_cap = 0;                      // longest list that is sure to leave every block below half full
+    uint64_t list_iters = 0, pair_spmspv_iters = 0, round_trips = 0;   // diagnostics of the last execute
+    // per-iteration timing of the last execute (HIP events on the program's stream / the communication stream)
+    std::vector<hipEvent_t> tev;                     // per iteration: start, messages packed, SpMV done, apply done, first slice in, last slice in
+    size_t tev_used = 0;
+    int rccl_ranks = 0;
     uint64_t bytes_sent = 0, bytes_dense = 0, exchanges = 0;   // since the last gt_dist_exchange_stats reset (sent: to other ranks and to itself)
 };
 
@@ -185,6 +273,90 @@ int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s
 
 static inline bool block_sparse(uint32_t count, uint32_t len) { return len != 0 && 2ull * count < len; }   // pairs cost 8 B, a dense message 4
 
+// waits for a stream with a deadline: an exchange that never completes (a peer died, a plan went wrong) must end the run with a
+// message, not hang it (GRAPHTAP_DIST_TIMEOUT_S, default 300)
+int sync_deadline(gt_dist *d, hipStream_t s, const char *what) {
+    static const double limit = getenv("GRAPHTAP_DIST_TIMEOUT_S") ? atof(getenv("GRAPHTAP_DIST_TIMEOUT_S")) : 300.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return GT_OK;
+        if (e != hipErrorNotReady) { gt_set_error("rank %d: %s failed: %s", d->rank, what, hipGetErrorString(e)); return GT_ERR_HIP; }
+        if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            gt_set_error("rank %d of %d: %s did not complete within %.0f s (a peer gone, or an exchange that does not match its plan)", d->rank, d->nranks, what, limit);
+            return GT_ERR_HIP;
+        }
+    }
+}
+
+// block tables of the graph an execute runs on (host + device), the CSR of send positions, the all-reduce words
+int tables_prepare(gt_dist *d, gt_program *p) {
+    const gt_graph *g = p->g;
+    if (d->sp_graph == g) return GT_OK;
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, NB = K * P;
+    d->stab.assign(NB, BlockTab{0, 0}); d->rtab.assign(NB, BlockTab{0, 0});
+    for (uint32_t k = 0; k < K; k++) {
+        uint64_t so = g->send_off[k], ro = g->recv_off[k];
+        for (uint32_t q = 0; q < P; q++) {
+            d->stab[k * P + q] = BlockTab{(uint32_t)so, g->send_counts[(size_t)k * P + q]};
+            d->rtab[k * P + q] = BlockTab{(uint32_t)ro, g->recv_counts[(size_t)k * P + q]};
+            so += g->send_counts[(size_t)k * P + q]; ro += g->recv_counts[(size_t)k * P + q];
+        }
+    }
+    for (void **q : {(void **)&d->d_stab, (void **)&d->d_cnt, (void **)&d->d_cur, (void **)&d->d_smode, (void **)&d->d_cx, (void **)&d->d_rtab, (void **)&d->d_ftab,
+                     (void **)&d->d_rsel, (void **)&d->d_flag, (void **)&d->d_words, (void **)&d->send_ptr, (void **)&d->send_pos})
+        if (*q) { (void)hipFree(*q); *q = nullptr; }
+    GT_HIP(hipMalloc((void **)&d->d_stab, NB * sizeof(BlockTab))); GT_HIP(hipMalloc((void **)&d->d_cnt, NB * 4)); GT_HIP(hipMalloc((void **)&d->d_cur, NB * 4));
+    GT_HIP(hipMalloc((void **)&d->d_smode, NB)); GT_HIP(hipMalloc((void **)&d->d_cx, 2ull * NB * 4));
+    GT_HIP(hipMalloc((void **)&d->d_rtab, NB * sizeof(BlockTab))); GT_HIP(hipMalloc((void **)&d->d_ftab, NB * sizeof(FrontTab)));
+    GT_HIP(hipMalloc((void **)&d->d_rsel, NB)); GT_HIP(hipMalloc((void **)&d->d_flag, 4));
+    d->nwords = 2 + P * NB;
+    GT_HIP(hipMalloc((void **)&d->d_words, (size_t)d->nwords * 8)); d->h_words.assign(d->nwords, 0);
+    GT_HIP(hipMemcpy(d->d_stab, d->stab.data(), NB * sizeof(BlockTab), hipMemcpyHostToDevice));
+    GT_HIP(hipMemcpy(d->d_rtab, d->rtab.data(), NB * sizeof(BlockTab), hipMemcpyHostToDevice));
+    if (d->pairs_send_cap < std::max<uint64_t>(g->send_elems, 1)) { if (d->pairs_send) GT_HIP(hipFree(d->pairs_send)); d->pairs_send = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_send, std::max<uint64_t>(g->send_elems, 1) * 8)); d->pairs_send_cap = std::max<uint64_t>(g->send_elems, 1); }
+    if (d->pairs_recv_cap < std::max<uint32_t>(g->ncols_total, 1)) { if (d->pairs_recv) GT_HIP(hipFree(d->pairs_recv)); d->pairs_recv = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_recv, (uint64_t)std::max<uint32_t>(g->ncols_total, 1) * 8)); d->pairs_recv_cap = std::max<uint32_t>(g->ncols_total, 1); }
+    d->cnt_send.assign(NB, 0); d->cnt_recv.assign(NB, 0); d->form_send.assign(NB, 0); d->form_recv.assign(NB, 0);
+    // send positions per owned column (min programs: the list -> pairs kernel walks them)
+    const uint32_t n = (uint32_t)g->send_elems, nc = g->info.nnzcols;
+    GT_HIP(hipMalloc((void **)&d->send_ptr, ((uint64_t)nc + 2) * 4)); GT_HIP(hipMalloc((void **)&d->send_pos, std::max<uint64_t>(n, 1) * 4));
+    if (n && !p->stationary) {
+        uint32_t *k1 = nullptr, *k2 = nullptr, *v1 = nullptr; void *tmp = nullptr;
+        GT_HIP(hipMalloc((void **)&k1, (uint64_t)n * 4)); GT_HIP(hipMalloc((void **)&k2, (uint64_t)n * 4)); GT_HIP(hipMalloc((void **)&v1, (uint64_t)n * 4));
+        const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096);
+        k_send_keys<<<grid, 256>>>(g->send_idx, n, k1, v1);
+        size_t tb = 0;
+        int bits = 1; while ((1ull << bits) < (uint64_t)nc + 1) bits++;
+        GT_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k1, k2, v1, d->send_pos, n, 0, bits, (hipStream_t)0));
+        GT_HIP(hipMalloc(&tmp, tb ? tb : 1));
+        GT_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k1, k2, v1, d->send_pos, n, 0, bits, (hipStream_t)0));
+        k_send_ptr<<<(unsigned)std::min<uint64_t>(((uint64_t)nc + 256) / 256, 4096), 256>>>(k2, n, nc, d->send_ptr);
+        GT_HIP(hipDeviceSynchronize());
+        (void)hipFree(k1); (void)hipFree(k2); (void)hipFree(v1); (void)hipFree(tmp);
+    } else GT_HIP(hipMemset(d->send_ptr, 0, ((uint64_t)nc + 2) * 4));
+    // a list of at most this many vertices leaves every block it touches below half full: pairs are then never more bytes than the dense block
+    uint32_t minlen = 0xFFFFFFFFu;
+    for (uint32_t b = 0; b < NB; b++) if (d->stab[b].len) minlen = std::min(minlen, d->stab[b].len);
+    d->list_send_cap = minlen == 0xFFFFFFFFu ? 0u : (minlen - 1) / 2;
+    const char *e = getenv("GRAPHTAP_DIST_LISTS");   // "1": lists of any length travel as pairs, "0": never
+    if (e && atoi(e) == 1) d->list_send_cap = 0x7FFFFFFFu;
+    if (e && atoi(e) == 0) d->list_send_cap = 0;
+    d->sp_graph = g;
+    return GT_OK;
+}
+
+// the blocks of x that arrive as pairs start from infinity(): only their active messages arrive (one launch for all of them)
+int fill_pair_blocks(gt_dist *d, gt_program *p, hipStream_t s) {
+    const uint32_t NB = (uint32_t)d->rtab.size();
+    uint32_t maxlen = 0;
+    for (uint32_t b = 0; b < NB; b++) if (d->form_recv[b]) maxlen = std::max(maxlen, d->rtab[b].len);
+    if (!maxlen) return GT_OK;
+    GT_HIP(hipMemcpyAsync(d->d_rsel, d->form_recv.data(), NB, hipMemcpyHostToDevice, s));
+    k_fill_blocks<<<dim3(std::min<uint32_t>((maxlen + 255) / 256, 1024), NB), 256, 0, s>>>((uint32_t *)p->x, d->d_rtab, d->d_rsel, GT_INF);
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+
 // min programs: counts the active messages of every send block, tells every peer, compacts the sparse blocks into pairs
 int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
     d->sparse_now = false;
@@ -192,25 +364,7 @@ int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
     const char *env = getenv("GRAPHTAP_SPARSE_EXCHANGE");
     if (p->stationary || p->x_bytes != 4 || (env && atoi(env) == 0)) return GT_OK;   // (the same decision on every rank)
     const uint32_t K = g->info.x_slices, P = g->info.nranks, NB = K * P;
-    if (d->sp_graph != g) {   // block tables of this graph
-        d->stab.assign(NB, BlockTab{0, 0}); d->rtab.assign(NB, BlockTab{0, 0});
-        for (uint32_t k = 0; k < K; k++) {
-            uint64_t so = g->send_off[k], ro = g->recv_off[k];
-            for (uint32_t q = 0; q < P; q++) {
-                d->stab[k * P + q] = BlockTab{(uint32_t)so, g->send_counts[(size_t)k * P + q]};
-                d->rtab[k * P + q] = BlockTab{(uint32_t)ro, g->recv_counts[(size_t)k * P + q]};
-                so += g->send_counts[(size_t)k * P + q]; ro += g->recv_counts[(size_t)k * P + q];
-            }
-        }
-        for (void *q : {(void *)d->d_stab, (void *)d->d_cnt, (void *)d->d_cur, (void *)d->d_smode, (void *)d->d_cx}) if (q) GT_HIP(hipFree(q));
-        GT_HIP(hipMalloc((void **)&d->d_stab, NB * sizeof(BlockTab))); GT_HIP(hipMalloc((void **)&d->d_cnt, NB * 4)); GT_HIP(hipMalloc((void **)&d->d_cur, NB * 4));
-        GT_HIP(hipMalloc((void **)&d->d_smode, NB)); GT_HIP(hipMalloc((void **)&d->d_cx, 2ull * NB * 4));
-        GT_HIP(hipMemcpy(d->d_stab, d->stab.data(), NB * sizeof(BlockTab), hipMemcpyHostToDevice));
-        if (d->pairs_send_cap < std::max<uint64_t>(g->send_elems, 1)) { if (d->pairs_send) GT_HIP(hipFree(d->pairs_send)); d->pairs_send = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_send, std::max<uint64_t>(g->send_elems, 1) * 8)); d->pairs_send_cap = std::max<uint64_t>(g->send_elems, 1); }
-        if (d->pairs_recv_cap < std::max<uint32_t>(g->ncols_total, 1)) { if (d->pairs_recv) GT_HIP(hipFree(d->pairs_recv)); d->pairs_recv = nullptr; GT_HIP(hipMalloc((void **)&d->pairs_recv, (uint64_t)std::max<uint32_t>(g->ncols_total, 1) * 8)); d->pairs_recv_cap = std::max<uint32_t>(g->ncols_total, 1); }
-        d->cnt_send.assign(NB, 0); d->cnt_recv.assign(NB, 0);
-        d->sp_graph = g;
-    }
+    { int st = tables_prepare(d, p); if (st != GT_OK) return st; }
     const uint32_t n = (uint32_t)g->send_elems;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096));
     GT_HIP(hipMemsetAsync(d->d_cnt, 0, NB * 4, s));
@@ -238,19 +392,17 @@ int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
         GT_HIP(hipStreamSynchronize(s));
         for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) d->cnt_recv[k * P + q] = in[q * K + k];
     }
-    std::vector<uint8_t> mode(NB);
     bool any = false;
-    for (uint32_t b = 0; b < NB; b++) { mode[b] = block_sparse(d->cnt_send[b], d->stab[b].len); any |= mode[b] != 0; }
+    for (uint32_t b = 0; b < NB; b++) {
+        d->form_send[b] = block_sparse(d->cnt_send[b], d->stab[b].len); any |= d->form_send[b] != 0;
+        d->form_recv[b] = block_sparse(d->cnt_recv[b], d->rtab[b].len);
+    }
     if (any) {
-        GT_HIP(hipMemcpyAsync(d->d_smode, mode.data(), NB, hipMemcpyHostToDevice, s));
+        GT_HIP(hipMemcpyAsync(d->d_smode, d->form_send.data(), NB, hipMemcpyHostToDevice, s));
         GT_HIP(hipMemsetAsync(d->d_cur, 0, NB * 4, s));
         k_block_compact<<<grid, 256, 0, s>>>((const uint32_t *)p->send, n, d->d_stab, NB, d->d_smode, d->d_cur, d->pairs_send);
-        GT_HIP(hipStreamSynchronize(s));   // `mode` is a host buffer
     }
-    // the sparse blocks of x start from infinity(): only their active messages arrive
-    for (uint32_t b = 0; b < NB; b++)
-        if (block_sparse(d->cnt_recv[b], d->rtab[b].len)) k_fill_u32<<<(d->rtab[b].len + 255) / 256, 256, 0, s>>>((uint32_t *)p->x + d->rtab[b].start, d->rtab[b].len, GT_INF);
-    GT_HIP(hipGetLastError());
+    { int st = fill_pair_blocks(d, p, s); if (st != GT_OK) return st; }
     d->sparse_now = true;
     return GT_OK;
 }
@@ -259,7 +411,7 @@ int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
 int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
     const gt_graph *g = p->g;
     const uint32_t K = g->info.x_slices, P = g->info.nranks, w = p->x_bytes;
-    { int st = sparse_prepare(d, p, s); if (st != GT_OK) return st; }
+    if (!d->lists_protocol) { int st = sparse_prepare(d, p, s); if (st != GT_OK) return st; }   // (the list protocol has counts and forms already)
     const bool sp = d->sparse_now;
     d->exchanges++;
     if (d->loop) {
@@ -276,7 +428,7 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
                 const uint32_t n = g->recv_counts[(size_t)k * P + src];
                 GT_REQUIRE(n == gs->send_counts[(size_t)k * P + d->rank], GT_ERR_STATE, "exchange plan mismatch between ranks %u and %d (slice %u)", src, d->rank, k);
                 const uint32_t cnt = sp ? d->cnt_recv[k * P + src] : 0;
-                if (sp && block_sparse(cnt, n)) {
+                if (sp && d->form_recv[k * P + src]) {
                     if (cnt) GT_HIP(hipMemcpyAsync(d->pairs_recv + dst, c.peer[src].pairs + off, (uint64_t)cnt * 8, hipMemcpyDeviceToDevice, s));
                 } else if (n) GT_HIP(hipMemcpyAsync((char *)p->x + dst * w, c.peer[src].send + off * w, (uint64_t)n * w, hipMemcpyDeviceToDevice, s));
                 dst += n;
@@ -284,7 +436,7 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
         }
         for (uint32_t b = 0; b < K * P; b++) {   // what this rank SENDS (the mirror image of the copies above)
             const uint32_t len = g->send_counts[b], cnt = sp ? d->cnt_send[b] : 0;
-            d->bytes_dense += (uint64_t)len * w; d->bytes_sent += (sp && block_sparse(cnt, len)) ? (uint64_t)cnt * 8 : (uint64_t)len * w;
+            d->bytes_dense += (uint64_t)len * w; d->bytes_sent += (sp && d->form_send[b]) ? (uint64_t)cnt * 8 : (uint64_t)len * w;
         }
         GT_HIP(hipStreamSynchronize(s));
         c.barrier();                                          // every rank has read every send buffer
@@ -301,9 +453,9 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
             const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
             const uint32_t cs = sp ? d->cnt_send[k * P + q] : 0, cr = sp ? d->cnt_recv[k * P + q] : 0;
             d->bytes_dense += (uint64_t)ns * w;
-            if (sp && block_sparse(cs, ns)) { if (cs) GT_NCCL(rccl()->Send(d->pairs_send + so, 2ull * cs, ncclUint32, (int)q, d->comm, d->comm_stream)); d->bytes_sent += 8ull * cs; }
+            if (sp && d->form_send[k * P + q]) { if (cs) GT_NCCL(rccl()->Send(d->pairs_send + so, 2ull * cs, ncclUint32, (int)q, d->comm, d->comm_stream)); d->bytes_sent += 8ull * cs; }
             else if (ns) { GT_NCCL(rccl()->Send((const char *)p->send + so * w, ns, ty, (int)q, d->comm, d->comm_stream)); d->bytes_sent += (uint64_t)ns * w; }
-            if (sp && block_sparse(cr, nr)) { if (cr) GT_NCCL(rccl()->Recv(d->pairs_recv + ro, 2ull * cr, ncclUint32, (int)q, d->comm, d->comm_stream)); }
+            if (sp && d->form_recv[k * P + q]) { if (cr) GT_NCCL(rccl()->Recv(d->pairs_recv + ro, 2ull * cr, ncclUint32, (int)q, d->comm, d->comm_stream)); }
             else if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
             so += ns; ro += nr;
         }
@@ -319,10 +471,164 @@ int exchange_consume(gt_dist *d, gt_program *p, uint32_t k, hipStream_t s) {
         for (uint32_t q = 0; q < P; q++) {
             const BlockTab t = d->rtab[k * P + q];
             const uint32_t cnt = d->cnt_recv[k * P + q];
-            if (block_sparse(cnt, t.len) && cnt) k_scatter_pairs<<<(cnt + 255) / 256, 256, 0, s>>>(d->pairs_recv + t.start, cnt, (uint32_t *)p->x + t.start);
+            if (d->form_recv[k * P + q] && cnt) k_scatter_pairs<<<(cnt + 255) / 256, 256, 0, s>>>(d->pairs_recv + t.start, cnt, (uint32_t *)p->x + t.start);
         }
         GT_HIP(hipGetLastError());
     }
+    return GT_OK;
+}
+
+// ---- the converge-mode loop of the min programs (BFS / SSSP / CC): frontier lists on every rank
+// After apply() every rank turns the list of the vertices it just changed into (index, value) pairs per destination block
+// (k_pairs_from_list; a list that is too long raises a flag instead), and ONE all-reduce carries the convergence count, the
+// flags and every block's pair count: one host round trip per iteration while the frontiers are lists (the reference's count
+// header, vp:766-773, rides its broadcasts the same way). A rank whose list did not fit packs dense messages and a second
+// all-reduce tells its counts (the iterations with large frontiers, whose compute dwarfs a round trip). A rank that received
+// nothing but pairs, few of them, runs the SpMSpV straight from the pairs (local column = block start + index) and applies
+// the rows it lowered; otherwise pairs are scattered into x and the streaming pass runs as before.
+int all_reduce_vec(gt_dist *d, hipStream_t s, const unsigned long long *extra_dev, unsigned long long *extra_host, const uint32_t *flag_dev, uint32_t *flag_host) {
+    d->round_trips++;
+    if (extra_dev) GT_HIP(hipMemcpyAsync(extra_host, extra_dev, 8, hipMemcpyDeviceToHost, s));   // this rank's own active count, before the sum
+    if (flag_dev) GT_HIP(hipMemcpyAsync(flag_host, flag_dev, 4, hipMemcpyDeviceToHost, s));
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        std::vector<unsigned long long> mine(d->nwords);
+        GT_HIP(hipMemcpyAsync(mine.data(), d->d_words, (size_t)d->nwords * 8, hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        c.peer[d->rank].words = mine.data();
+        c.barrier();
+        for (uint32_t i = 0; i < d->nwords; i++) { unsigned long long t = 0; for (int r = 0; r < c.n; r++) t += c.peer[r].words[i]; d->h_words[i] = t; }
+        c.barrier();
+        return GT_OK;
+    }
+    GT_NCCL(rccl()->AllReduce(d->d_words, d->d_words, d->nwords, ncclUint64, ncclSum, d->comm, s));
+    GT_HIP(hipMemcpyAsync(d->h_words.data(), d->d_words, (size_t)d->nwords * 8, hipMemcpyDeviceToHost, s));
+    return sync_deadline(d, s, "the per-iteration all-reduce (convergence word + pair counts)");
+}
+// counts and forms of what I send / receive, out of the all-reduced words
+void take_counts(gt_dist *d, uint32_t NB) {
+    const uint32_t P = (uint32_t)d->nranks, K = NB / P, me = (uint32_t)d->rank;
+    for (uint32_t b = 0; b < NB; b++) {
+        const unsigned long long w = d->h_words[2 + (size_t)me * NB + b];
+        d->cnt_send[b] = (uint32_t)w; d->form_send[b] = (uint8_t)((w >> 32) & 1u);
+    }
+    for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) {   // block (k, source q) of x = block (k, me) of rank q's send buffer
+        const unsigned long long w = d->h_words[2 + (size_t)q * NB + k * P + me];
+        d->cnt_recv[k * P + q] = (uint32_t)w; d->form_recv[k * P + q] = (uint8_t)((w >> 32) & 1u);
+    }
+}
+// this rank's messages for the coming iteration: pairs from its list if the list is short enough (decided on the device), and
+// the words of the all-reduce. `d_active` = the device word of the apply just launched (null before the first iteration).
+int lists_prepare_send(gt_dist *d, gt_program *p, hipStream_t s, const unsigned long long *d_active) {
+    const gt_graph *g = p->g;
+    const uint32_t NB = (uint32_t)d->stab.size();
+    GT_HIP(hipMemsetAsync(d->d_cur, 0, NB * 4, s));
+    GT_HIP(hipMemsetAsync(d->d_flag, 0, 4, s));
+    // the list the apply just launched is writing (deferred apply: fl_cur is flipped by apply_end afterwards), or the initial one
+    const int li = d_active ? (p->fl_cur ^ 1) : p->fl_cur;
+    const bool may = p->fl_enabled && (d_active != nullptr || p->fl_cur_valid);
+    if (may) {
+        const uint32_t cap = std::min(d->list_send_cap, p->fl_cap);
+        k_pairs_from_list<<<1024, 256, 0, s>>>(p->fl_v[li], p->d_fl + li, cap, g->IJ, g->JV, d->send_ptr, d->send_pos, p->s0, g->info.rank * g->info.tile_height,
+                                               gt_vidmap_of(g), p->prm.kind, d->d_stab, NB, d->d_cur, d->pairs_send, d->d_flag);
+    } else {
+        static const uint32_t one = 1;
+        GT_HIP(hipMemcpyAsync(d->d_flag, &one, 4, hipMemcpyHostToDevice, s));
+    }
+    k_words<<<(d->nwords + 255) / 256, 256, 0, s>>>(d->d_words, d->nwords, d_active, d->d_flag, d->d_cur, nullptr, (uint32_t)d->rank, NB);
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+// the dense round of a rank whose list did not fit: messages of all owned columns, packed; per-block counts; the blocks that are
+// sparse by the byte rule compacted into pairs; words for the second all-reduce
+int dense_prepare_send(gt_dist *d, gt_program *p, hipStream_t s, bool i_need_dense) {
+    const gt_graph *g = p->g;
+    const uint32_t NB = (uint32_t)d->stab.size(), n = (uint32_t)g->send_elems;
+    if (i_need_dense) {
+        int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096));
+        GT_HIP(hipMemsetAsync(d->d_cnt, 0, NB * 4, s));
+        k_block_active<<<grid, 256, 0, s>>>((const uint32_t *)p->send, n, d->d_stab, NB, d->d_cnt);
+        // forms by the byte rule, on the host: this rank's own counts are needed for it (a local read; the peers learn them from the all-reduce)
+        GT_HIP(hipMemcpyAsync(d->cnt_send.data(), d->d_cnt, NB * 4, hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        bool any = false;
+        for (uint32_t b = 0; b < NB; b++) { d->form_send[b] = block_sparse(d->cnt_send[b], d->stab[b].len); any |= d->form_send[b] != 0; }
+        GT_HIP(hipMemcpyAsync(d->d_smode, d->form_send.data(), NB, hipMemcpyHostToDevice, s));
+        if (any) {
+            GT_HIP(hipMemsetAsync(d->d_cur, 0, NB * 4, s));
+            k_block_compact<<<grid, 256, 0, s>>>((const uint32_t *)p->send, n, d->d_stab, NB, d->d_smode, d->d_cur, d->pairs_send);
+        }
+        k_words<<<(d->nwords + 255) / 256, 256, 0, s>>>(d->d_words, d->nwords, nullptr, nullptr, d->d_cnt, d->d_smode, (uint32_t)d->rank, NB);
+    } else {   // my pairs stand: the same counts again (every block in pair form)
+        k_words<<<(d->nwords + 255) / 256, 256, 0, s>>>(d->d_words, d->nwords, nullptr, nullptr, d->d_cur, nullptr, (uint32_t)d->rank, NB);
+    }
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+// the SpMV of a rank that received nothing but (few) pairs: the frontier is the pairs themselves
+int combine_from_pairs(gt_dist *d, gt_program *p, hipStream_t s, uint32_t total) {
+    const gt_graph *g = p->g;
+    const uint32_t NB = (uint32_t)d->rtab.size(), K = g->info.x_slices;
+    if (!d->loop) for (uint32_t k = 0; k < K; k++) GT_HIP(hipStreamWaitEvent(s, d->ev_slice[k], 0));
+    GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
+    p->fl_rows_valid = true;
+    if (total == 0) return GT_OK;   // nothing is active for this tile-row: y keeps its running minima
+    d->h_ftab.resize(NB);   // (a member: the copy below may read it after this function returned; it is rewritten after the next round trip)
+    uint32_t o = 0;
+    for (uint32_t b = 0; b < NB; b++) { d->h_ftab[b] = FrontTab{o, d->cnt_recv[b]}; o += d->cnt_recv[b]; }
+    GT_HIP(hipMemcpyAsync(d->d_ftab, d->h_ftab.data(), NB * sizeof(FrontTab), hipMemcpyHostToDevice, s));
+    if (p->fr_cap < total + 1) { int st = gt_spmspv_reserve(p, total); if (st != GT_OK) return st; }
+    k_pairs_frontier<<<(unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 4096), 256, 0, s>>>(d->pairs_recv, d->d_rtab, d->d_ftab, NB, total, g->JA,
+                                                                                                      p->fr_col, p->fr_val, p->fr_off);
+    GT_HIP(hipGetLastError());
+    d->pair_spmspv_iters++;
+    return gt_spmspv_run_frontier(p, total, s);
+}
+
+int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::steady_clock::time_point t0) {
+    const gt_graph *g = p->g;
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, NB = K * P;
+    hipStream_t s = p->stream;
+    { int st = tables_prepare(d, p); if (st != GT_OK) return st; }
+    if (d->loop) d->loop->peer[d->rank].pairs = d->pairs_send;
+    d->lists_protocol = true; d->sparse_now = true;
+    d->list_iters = d->pair_spmspv_iters = d->round_trips = 0;
+    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    const int spm = senv ? atoi(senv) : -1;   // 0: never the SpMSpV from pairs, 1: whenever everything arrived as pairs, unset: by size
+    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
+    // the messages of iteration 0
+    int st = lists_prepare_send(d, p, s, nullptr); if (st != GT_OK) return st;
+    unsigned long long local_active = 0; uint32_t my_flag = 0;
+    st = all_reduce_vec(d, s, nullptr, nullptr, d->d_flag, &my_flag); if (st != GT_OK) return st;
+    for (;;) {
+        if (d->h_words[1] != 0) {   // somebody's list did not fit: the dense round
+            st = dense_prepare_send(d, p, s, my_flag != 0); if (st != GT_OK) return st;
+            st = all_reduce_vec(d, s, nullptr, nullptr, nullptr, nullptr); if (st != GT_OK) return st;
+        } else d->list_iters++;
+        if (my_flag == 0) p->x_stale = true;   // no messenger ran for this iteration: the next dense one rewrites every message
+        take_counts(d, NB);
+        uint64_t total = 0; bool all_pairs = true;
+        for (uint32_t b = 0; b < NB; b++) { if (d->form_recv[b]) total += d->cnt_recv[b]; else if (d->rtab[b].len) all_pairs = false; }
+        const bool from_pairs = all_pairs && spm != 0 && total < 0x7FFFFFFFull && (spm == 1 || total * 8 <= g->info.nnz_local / frac);
+        if (!from_pairs) { st = fill_pair_blocks(d, p, s); if (st != GT_OK) return st; }
+        st = exchange_issue(d, p, s); if (st != GT_OK) return st;
+        if (from_pairs) {
+            st = combine_from_pairs(d, p, s, (uint32_t)total); if (st != GT_OK) return st;
+        } else {
+            for (uint32_t k = 0; k < K; k++) {
+                st = exchange_consume(d, p, k, s); if (st != GT_OK) return st;
+                st = (K > 1) ? gt_program_combine_slice(p, k) : gt_program_combine(p); if (st != GT_OK) return st;
+            }
+        }
+        st = gt_program_apply_begin(p, 0); if (st != GT_OK) return st;
+        st = lists_prepare_send(d, p, s, p->d_active); if (st != GT_OK) return st;
+        st = all_reduce_vec(d, s, p->d_active, &local_active, d->d_flag, &my_flag); if (st != GT_OK) return st;   // the host round trip of the iteration
+        st = gt_program_apply_end(p, local_active); if (st != GT_OK) return st;
+        p->last_active = d->h_words[0];
+        if (d->h_words[0] == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }   // has_converged, vp:1918
+    }
+    d->lists_protocol = false; d->sparse_now = false;
     return GT_OK;
 }
 
@@ -420,7 +726,9 @@ int gt_dist_free(gt_dist *d) {
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     if (d->d_word) (void)hipFree(d->d_word);
     if (d->tmp) (void)hipFree(d->tmp);
-    for (void *q : {(void *)d->d_stab, (void *)d->d_cnt, (void *)d->d_cur, (void *)d->d_smode, (void *)d->d_cx, (void *)d->pairs_send, (void *)d->pairs_recv}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)d->d_stab, (void *)d->d_cnt, (void *)d->d_cur, (void *)d->d_smode, (void *)d->d_cx, (void *)d->pairs_send, (void *)d->pairs_recv, (void *)d->d_rtab,
+                    (void *)d->d_ftab, (void *)d->d_rsel, (void *)d->d_flag, (void *)d->d_words, (void *)d->send_ptr, (void *)d->send_pos}) if (q) (void)hipFree(q);
+    for (hipEvent_t e : d->tev) (void)hipEventDestroy(e);
     delete d;
     return GT_OK;
 }
@@ -458,7 +766,11 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     k_dist_preload<<<1, 64, 0, s>>>();   // this file's code object is loaded at its first launch (milliseconds): not inside the timed loop
     GT_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
+    const char *penv = getenv("GRAPHTAP_DIST_PROTOCOL");   // "dense": the loop below for every program (A/B, tests)
+    const char *sxenv = getenv("GRAPHTAP_SPARSE_EXCHANGE");   // "0": every block dense (the loop below)
+    const bool lists = check && !col && !p->stationary && p->fl_enabled && !(penv && strcmp(penv, "dense") == 0) && !(sxenv && atoi(sxenv) == 0);
+    if (lists) { int st = lists_execute(d, p, stats, t0); if (st != GT_OK) { d->lists_protocol = false; d->sparse_now = false; return st; } }
+    else for (;;) {
         int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
         if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; }
         if (!col && !p->converged) {
@@ -486,7 +798,8 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         double ms = 0; uint32_t n = 0;
         (void)gt_program_timing(p, &ms, &n, 1);
-        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = 0;
+        stats->spmv_ms = ms; stats->spmv_launches = n; stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered;
+        stats->list_iterations = lists ? (uint32_t)d->list_iters : 0;
     }
     return GT_OK;
 }

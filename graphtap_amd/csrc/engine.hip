@@ -405,17 +405,19 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
     int st = gt_ingest(g, dev_edges, m, weighted);
     tick("ingest (TCSC tile-row)", tb);
     if (staged) (void)hipFree(staged);
-    if (st != GT_OK) { gt_graph_free(g); return st; }
+    if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
     const char *env = getenv("GRAPHTAP_SPMV");
     g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : (env && strcmp(env, "pb_f32msg") == 0) ? GT_SPMV_PB_F32MSG : GT_SPMV_PB;
     st = gt_layout_build(g);
-    if (st != GT_OK) { gt_graph_free(g); return st; }
+    if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
     tick("layout of x", tb);
     if (g->spmv_variant != GT_SPMV_EDGE) {
         st = gt_pb_build(g);
-        if (st != GT_OK) { gt_graph_free(g); return st; }
+        if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
         tick("propagation-blocking streams", tb);
     }
+    gt_scratch_release();   // the build's scratch pool goes back to the driver
+    tick("scratch pool released", tb);
     *out = g;
     return GT_OK;
 }
@@ -425,6 +427,7 @@ int gt_graph_select_spmv(gt_graph *g, int variant) {
     GT_REQUIRE(variant >= GT_SPMV_EDGE && variant <= GT_SPMV_PB_F32MSG, GT_ERR_INVALID, "unknown SpMV variant %d", variant);
     if (variant != GT_SPMV_EDGE && !g->pb) {
         int st = gt_pb_build(g);
+        gt_scratch_release();
         if (st != GT_OK) return st;
     }
     g->spmv_variant = variant;
@@ -536,16 +539,17 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
               hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
-    {   // frontier lists: min programs on one rank (the multi-rank drivers run the sliced combine, which has no sparse path)
+    {   // frontier lists of the min programs: the vertices the last apply changed (on several ranks: the rank's own, local ids;
+        // the C++ driver turns them into (index, value) pairs for the peers and runs the SpMSpV from the pairs it receives, dist.hip)
         const char *fe = getenv("GRAPHTAP_FRONTIER_LISTS");
-        p->fl_enabled = !p->stationary && !gt_has_exchange(g) && g->info.nranks == 1 && !(fe && atoi(fe) == 0);
+        p->fl_enabled = !p->stationary && prm->order == GT_ROW && !(fe && atoi(fe) == 0);
         if (ok && p->fl_enabled) {
             p->fl_rows_cap = std::max<uint32_t>(g->info.nnzrows, 1);
             p->fl_cap = std::max<uint32_t>(std::min<uint32_t>(H, GT_FRONTIER_CAP), 1);   // a list never holds more than the segment's H vertices
             ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)p->fl_cap * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)p->fl_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->fl_rows, (uint64_t)p->fl_rows_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess;
-            if (ok && prm->kind == GT_BFS && !g->flags.directed)   // symmetric graph: bottom-up steps are possible (kernels.hip)
+            if (ok && prm->kind == GT_BFS && !g->flags.directed && !gt_has_exchange(g))   // symmetric graph, whole on one rank: bottom-up steps are possible (kernels.hip)
                 ok = hipMalloc((void **)&p->bu_rows, (uint64_t)std::max<uint32_t>(g->info.nnzrows, 1) * 4) == hipSuccess;
         }
     }
@@ -611,11 +615,16 @@ static int init_common(gt_program *p) {
                 GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)g->info.nnzrows / 32 + 1) * 4, s));
                 GT_HIP(hipMemsetAsync(p->d_fl, 0, 4 * sizeof(unsigned int), s));
                 p->fl_cur = 0; p->fl_prev_valid = true; p->fl_prev_n = 0; p->fl_rows_valid = false; p->list_iters = 0;
-                p->bfs_settled = (p->prm.root < H) ? 1 : 0; p->bottom_up_iters = 0; p->x_deferred = false; p->x_stale = false;
+                p->bottom_up_iters = 0; p->x_deferred = false; p->x_stale = false;
                 p->fl_cur_valid = p->prm.kind != GT_CC; p->fl_cur_n = 0;
-                if (p->fl_cur_valid && p->prm.root < H) {   // one rank: slot index = vertex id
+                // the root's place in this rank's segment, if it lives here (one rank: the vertex id itself)
+                const uint64_t uroot = (g->perm_mask == 0xFFFFFFFFu) ? p->prm.root : (uint64_t)((p->prm.root * g->perm_a) & g->perm_mask);
+                const bool root_here = p->prm.root < g->info.nrows && uroot >= base && uroot < (uint64_t)base + H;
+                const uint32_t root_local = (uint32_t)(uroot - base);
+                p->bfs_settled = root_here ? 1 : 0;
+                if (p->fl_cur_valid && root_here) {
                     const unsigned int one = 1;
-                    GT_HIP(hipMemcpyAsync(p->fl_v[0], &p->prm.root, 4, hipMemcpyHostToDevice, s));
+                    GT_HIP(hipMemcpyAsync(p->fl_v[0], &root_local, 4, hipMemcpyHostToDevice, s));
                     GT_HIP(hipMemcpyAsync(p->d_fl, &one, sizeof(one), hipMemcpyHostToDevice, s));
                     GT_HIP(hipStreamSynchronize(s));   // `one` is on this stack frame
                     p->fl_cur_n = 1;
@@ -933,14 +942,15 @@ int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int re
     return GT_OK;
 }
 
-int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
-    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "apply before initialize");
+// apply() in two halves. apply_launch enqueues the kernels (the active count stays on the device, the vertices that change are
+// appended to the next frontier list); apply_finish does the host bookkeeping once somebody has read the count. gt_program_apply
+// reads it at once; the multi-rank driver (dist.hip) reads it together with the all-reduced convergence word -- one host round
+// trip per iteration.
+static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active, bool deferred, bool *list_from_flags_out) {
     const gt_graph *g = p->g;
     hipStream_t s = p->stream;
     const uint32_t nr = g->info.nnzrows, H = g->info.tile_height;
-    // converged: apply_*() is skipped (vp:1616-1632) but the driver still counts the trip (vp:421), so a later
-    // execute(n) terminates
-    if (p->converged) { p->iteration++; p->fused = false; p->fuse_armed = false; if (active) *active = 0; return GT_OK; }
+    int dummy_active = 0; int *active = want_active ? &dummy_active : nullptr;   // (only tested against null below)
     unsigned long long *d_active = active ? p->d_active : nullptr;   // counted only when the caller wants it (converge mode)
     const bool fused = p->fused;   // phase 2 already applied the rows of its single-workgroup bins (and counted them)
     p->fused = false; p->fuse_armed = false; p->cf_hint = false;
@@ -992,7 +1002,9 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
             } else {
                 if (nr && bfs) k_apply_rows<true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
                 else if (nr) k_apply_rows<false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
-                list_from_flags = lists;   // once the count is known (below)
+                list_from_flags = lists;   // once the count is known (apply_finish) -- or at once when nobody is going to read it first
+                if (lists && deferred && nr)   // (the kernel stops appending at the list's capacity; the count tells whether the list is whole)
+                    k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, next, next_n, p->fl_cap);
             }
             p->fl_rows_valid = false;
             break;
@@ -1000,18 +1012,22 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     }
     GT_HIP(hipGetLastError());
     p->iteration++;  // vp:421
-    if (active) {
-        unsigned long long h = 0;
-        GT_HIP(hipMemcpyAsync(&h, p->d_active, sizeof(h), hipMemcpyDeviceToHost, s));
-        GT_HIP(hipStreamSynchronize(s));
-        *active = h;
+    *list_from_flags_out = list_from_flags && !deferred;
+    return GT_OK;
+}
+// `h`: the active count of the apply just launched (ignored unless it was counted)
+static int apply_finish(gt_program *p, bool counted, unsigned long long h, bool list_from_flags) {
+    const gt_graph *g = p->g;
+    hipStream_t s = p->stream;
+    const uint32_t nr = g->info.nnzrows;
+    if (counted) {
         p->last_active = h;
         if (p->prm.kind == GT_BFS) p->bfs_settled += h;
     } else p->last_active = ~0ull;
     if (p->fl_enabled && !p->stationary) {   // the list of the vertices this apply changed becomes the current frontier
         p->fl_prev_valid = p->fl_cur_valid; p->fl_prev_n = p->fl_cur_n;
         p->fl_cur ^= 1;
-        p->fl_cur_valid = active != nullptr && p->last_active <= p->fl_cap;
+        p->fl_cur_valid = counted && p->last_active <= p->fl_cap;
         p->fl_cur_n = p->fl_cur_valid ? (uint32_t)p->last_active : 0;
         if (p->fl_cur_valid && list_from_flags && nr && p->fl_cur_n)   // a full apply that changed few: collect them
             k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur, p->fl_cap);
@@ -1019,6 +1035,30 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     }
     return GT_OK;
 }
+
+int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
+    GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "apply before initialize");
+    // converged: apply_*() is skipped (vp:1616-1632) but the driver still counts the trip (vp:421), so a later
+    // execute(n) terminates
+    if (p->converged) { p->iteration++; p->fused = false; p->fuse_armed = false; if (active) *active = 0; return GT_OK; }
+    bool lff = false;
+    int st = apply_launch(p, num_iterations, active != nullptr, false, &lff);
+    if (st != GT_OK) return st;
+    unsigned long long h = 0;
+    if (active) {
+        GT_HIP(hipMemcpyAsync(&h, p->d_active, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+        GT_HIP(hipStreamSynchronize(p->stream));
+        *active = h;
+    }
+    return apply_finish(p, active != nullptr, h, lff);
+}
+// the two halves for a driver that reads the count itself (device word: gt_program_active_word); converge mode only
+int gt_program_apply_begin(gt_program *p, uint32_t num_iterations) {
+    GT_REQUIRE(p && p->initialized && !p->converged, GT_ERR_STATE, "apply_begin: program not running");
+    bool lff = false;
+    return apply_launch(p, num_iterations, true, true, &lff);
+}
+int gt_program_apply_end(gt_program *p, uint64_t active_local) { return apply_finish(p, true, active_local, false); }
 
 int gt_program_finish_converged(gt_program *p) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "finish before initialize");

@@ -30,18 +30,43 @@ void gt_set_error(const char *fmt, ...);
 // hipMalloc / hipFree of the build scratch, with the time they take (printed by the [build] lines of GRAPHTAP_PB_STATS)
 struct gt_alloc_clock { double malloc_ms = 0, free_ms = 0; uint64_t mallocs = 0, frees = 0, bytes = 0; };
 inline gt_alloc_clock &gt_alloc_clock_ref() { static gt_alloc_clock c; return c; }
+// The build scratch (ingest + propagation-blocking build: ~54 buffers, 70 GB in all at R-MAT-26, a few alive at a time) comes
+// from a POOL: a freed block is kept and handed to the next request it fits (same size or up to 2x larger -- the builds ask for
+// the same few sizes, nnz x 4 / 8, again and again), and the pool is emptied when the graph is built (gt_scratch_release).
+// A multi-GB hipMalloc stalls for seconds now and then on this pool: the fewer of them, the smaller that exposure.
+struct gt_scratch_pool { struct Blk { void *p; uint64_t bytes; bool busy; }; std::vector<Blk> blocks; uint64_t reused = 0; };
+inline gt_scratch_pool &gt_scratch_pool_ref() { static thread_local gt_scratch_pool pool; return pool; }
 inline hipError_t gt_scratch_malloc(void **p, uint64_t bytes) {
+    gt_scratch_pool &pool = gt_scratch_pool_ref();
+    gt_scratch_pool::Blk *best = nullptr;
+    for (auto &b : pool.blocks)
+        if (!b.busy && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; *p = best->p; pool.reused++; return hipSuccess; }
     const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {   // out of memory with idle blocks in the pool: give them back and try once more
+        bool freed = false;
+        for (auto it = pool.blocks.begin(); it != pool.blocks.end();) { if (!it->busy) { (void)hipFree(it->p); it = pool.blocks.erase(it); freed = true; } else ++it; }
+        if (freed) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+    }
     gt_alloc_clock &c = gt_alloc_clock_ref();
     c.malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c.mallocs++; c.bytes += bytes;
+    if (e == hipSuccess) pool.blocks.push_back({*p, bytes, true});
     return e;
 }
 inline void gt_scratch_free(void *p) {
-    const auto t0 = std::chrono::steady_clock::now();
+    if (!p) return;
+    gt_scratch_pool &pool = gt_scratch_pool_ref();
+    for (auto &b : pool.blocks) if (b.p == p) { b.busy = false; return; }   // stays in the pool until gt_scratch_release
     (void)hipFree(p);
+}
+// end of a build: every idle block goes back to the driver (blocks still in use -- there should be none -- are left alone)
+inline void gt_scratch_release() {
+    gt_scratch_pool &pool = gt_scratch_pool_ref();
+    const auto t0 = std::chrono::steady_clock::now();
     gt_alloc_clock &c = gt_alloc_clock_ref();
-    c.free_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c.frees++;
+    for (auto it = pool.blocks.begin(); it != pool.blocks.end();) { if (!it->busy) { (void)hipFree(it->p); c.frees++; it = pool.blocks.erase(it); } else ++it; }
+    c.free_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 // Owned tile-row of the reference's p x p grid, in HBM.
@@ -251,6 +276,12 @@ int gt_kernels_preload(hipStream_t s);
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
 extern "C" int gt_min_messenger(gt_program *p);      // the messenger of BFS / SSSP / CC, now (engine.hip, inside its extern "C" block; not part of the ABI header)   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
+// the SpMSpV over a frontier a driver put into fr_col / fr_val / fr_off (= entry counts) itself (several ranks: the (index, value)
+// pairs its peers sent, dist.hip): y lowered with atomics, the rows it lowered left in fl_rows for the row-list apply
+int gt_spmspv_run_frontier(gt_program *p, uint32_t nact, hipStream_t s);
+// apply() in two halves for a driver that reads the active count itself, together with other words (dist.hip)
+extern "C" int gt_program_apply_begin(gt_program *p, uint32_t num_iterations);
+extern "C" int gt_program_apply_end(gt_program *p, uint64_t active_local);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
 // owner/epoch: the program (and its initialize() count) issuing the SpMV, or null for a stand-alone gt_spmv; lets the
 // min programs skip chunks without an active column (activity filtering)

@@ -442,12 +442,14 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     // 0.39 ms for the SpMSpV from the list); small frontiers: the list first
     const bool bottom_up_first = p->last_active != ~0ull && p->last_active > 65536;
     if (bottom_up_first) { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
-    if (p->fl_enabled && p->fl_cur_valid) {
+    // (under the exchange layout the frontier is what the peers sent, not this rank's list: dist.hip runs that SpMSpV from the pairs)
+    const bool own_list = p->fl_enabled && p->fl_cur_valid && !gt_has_exchange(g);
+    if (own_list) {
         int st = spmspv_from_list(p, s, force, done);
         if (st != GT_OK || *done) return st;
     }
     if (!bottom_up_first) { int st = bfs_bottom_up_try(p, s, done); if (st != GT_OK || *done) return st; }
-    if (p->fl_enabled && p->fl_cur_valid) return GT_OK;
+    if (own_list) return GT_OK;
     // counting the frontier costs a pass over x and a device round trip: only worth it when the previous apply() (whose
     // count the converge-mode driver reads anyway) activated few vertices
     static const uint64_t max_active = getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_MAX_ACTIVE")) : 16384;
@@ -517,14 +519,26 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
     if (!force && h[1] > g->info.nnz_local / frac) return GT_OK;   // the streaming pass does it (x is complete either way)
     GT_REQUIRE(h[1] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "frontier entry offsets exceed 32 bits");
+    int st = gt_spmspv_run_frontier(p, nact, s);
+    if (st != GT_OK) return st;
+    *done = true;
+    return GT_OK;
+}
+
+// fr_col / fr_val hold the frontier's columns and messages, fr_off their entry counts (nact of them); d_fl[2] (the length of
+// fl_rows) must be zero. The total entry count stays on the device.
+int gt_spmspv_run_frontier(gt_program *p, uint32_t nact, hipStream_t s) {
+    const gt_graph *g = p->g;
+    const unsigned grid = (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)nact + TPB - 1) / TPB, 4096), 1);
     const bool weighted = p->semiring == GT_MINPLUS_U32;
     uint32_t *marks = (uint32_t *)p->row_mark;
     // the short columns: eight lanes each
     constexpr uint32_t BIG = 2048;
-    const unsigned gc = (unsigned)std::min<uint64_t>(((uint64_t)nact + TPB / 8 - 1) / (TPB / 8), 256u * 64u);
+    const unsigned gc = (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)nact + TPB / 8 - 1) / (TPB / 8), 256u * 64u), 1);
     if (weighted) k_spmspv_cols<true><<<gc, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, BIG, g->JA, g->IA, g->A, (uint32_t *)p->y, marks);
     else k_spmspv_cols<false><<<gc, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, BIG, g->JA, g->IA, nullptr, (uint32_t *)p->y, marks);
     // the long ones (hubs): one thread per entry
+    GT_HIP(hipMemsetAsync(p->d_frontier + 2, 0, sizeof(unsigned long long), s));
     k_keep_big<<<grid, TPB, 0, s>>>(p->fr_off, nact, BIG, p->d_frontier + 2);
     {
         size_t tb = 0;
@@ -532,7 +546,7 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
         if (tb > p->fr_tmp_bytes) { if (p->fr_tmp) GT_HIP(hipFree(p->fr_tmp)); p->fr_tmp = nullptr; GT_HIP(hipMalloc(&p->fr_tmp, tb)); p->fr_tmp_bytes = tb; p->spmspv_allocs++; }
         GT_HIP(hipcub::DeviceScan::ExclusiveSum(p->fr_tmp, tb, p->fr_off, p->fr_off, nact, s));
     }
-    const unsigned g2 = (unsigned)std::min<uint64_t>((h[1] + TPB - 1) / TPB, 256u * 16u);   // at most h[1] entries are long columns'; the kernel reads the exact count
+    const unsigned g2 = 256u * 16u;   // the kernel reads the number of long-column entries from the device
     if (weighted) k_spmspv_min<true, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, 0, p->d_frontier + 2, g->JA, g->IA, g->A, (uint32_t *)p->y, marks);
     else k_spmspv_min<false, true><<<g2, TPB, 0, s>>>(p->fr_col, p->fr_val, p->fr_off, nact, 0, p->d_frontier + 2, g->JA, g->IA, nullptr, (uint32_t *)p->y, marks);
     // the rows either kernel lowered, in ascending order
@@ -541,7 +555,6 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     GT_HIP(hipGetLastError());
     p->spmspv_iters++;
     p->fl_rows_valid = true;
-    *done = true;
     return GT_OK;
 }
 
@@ -557,8 +570,9 @@ int gt_frontier_messages(gt_program *p, hipStream_t s) {
     const gt_graph *g = p->g;
     const unsigned int *n_prev = p->d_fl + (p->fl_cur ^ 1), *n_cur = p->d_fl + p->fl_cur;
     auto grid = [](uint32_t n) { return (unsigned)std::max<uint64_t>(std::min<uint64_t>(((uint64_t)n + TPB - 1) / TPB, 4096), 1); };
-    if (p->fl_prev_n) k_list_reset_x<<<grid(p->fl_prev_n), TPB, 0, s>>>((uint32_t *)p->x, p->fl_v[p->fl_cur ^ 1], n_prev, g->IJ, g->JV, g->xslot);
-    if (p->fl_cur_n) k_list_msg<<<grid(p->fl_cur_n), TPB, 0, s>>>((uint32_t *)p->x, p->fl_v[p->fl_cur], n_cur, g->IJ, g->JV, g->xslot, p->s0,
+    uint32_t *xm = (uint32_t *)(p->xseg ? p->xseg : p->x);   // several ranks: the owned columns' messages (packed per destination afterwards)
+    if (p->fl_prev_n) k_list_reset_x<<<grid(p->fl_prev_n), TPB, 0, s>>>(xm, p->fl_v[p->fl_cur ^ 1], n_prev, g->IJ, g->JV, g->xslot);
+    if (p->fl_cur_n) k_list_msg<<<grid(p->fl_cur_n), TPB, 0, s>>>(xm, p->fl_v[p->fl_cur], n_cur, g->IJ, g->JV, g->xslot, p->s0,
                                                                    g->info.rank * g->info.tile_height, gt_vidmap_of(g), p->prm.kind);
     GT_HIP(hipGetLastError());
     return GT_OK;

@@ -917,15 +917,15 @@ int gt_layout_build(gt_graph *g) {
     // (SSSP: direct stores) keep 24, where 12 was 3-4 % slower; BFS / CC are indifferent.
     const char *et = getenv("GRAPHTAP_PB_HUB_DEG");
     const uint32_t thr = et ? (uint32_t)atoi(et) : (g->info.weighted ? 24u : 12u);
-    struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } deg, hubflag, tailflag, hubpos, tailpos, key, key2, col, col2, tmp;
-    for (Buf *b : {&deg, &hubflag, &tailflag, &hubpos, &tailpos}) LAY_HIP(hipMalloc(&b->p, (uint64_t)(nc + 1) * 4));
+    struct Buf { void *p = nullptr; ~Buf() { if (p) gt_scratch_free(p); } } deg, hubflag, tailflag, hubpos, tailpos, key, key2, col, col2, tmp;
+    for (Buf *b : {&deg, &hubflag, &tailflag, &hubpos, &tailpos}) LAY_HIP(gt_scratch_malloc(&b->p, (uint64_t)(nc + 1) * 4));
     LAY_HIP(hipMemsetAsync(hubflag.p, 0, (uint64_t)(nc + 1) * 4, s));
     LAY_HIP(hipMemsetAsync(tailflag.p, 0, (uint64_t)(nc + 1) * 4, s));
     k_col_degrees<<<grid_for(nc), TPB, 0, s>>>(g->JA, nc, thr, (uint32_t *)deg.p, (uint32_t *)hubflag.p, (uint32_t *)tailflag.p);
     {
         size_t tb = 0;
         LAY_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint32_t *)hubflag.p, (uint32_t *)hubpos.p, nc + 1, s));
-        LAY_HIP(hipMalloc(&tmp.p, tb ? tb : 1));
+        LAY_HIP(gt_scratch_malloc(&tmp.p, tb ? tb : 1));
         LAY_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, (uint32_t *)hubflag.p, (uint32_t *)hubpos.p, nc + 1, s));
         LAY_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, (uint32_t *)tailflag.p, (uint32_t *)tailpos.p, nc + 1, s));
     }
@@ -940,12 +940,12 @@ int gt_layout_build(gt_graph *g) {
     LAY_HIP(hipMalloc((void **)&g->xcol, std::max<uint64_t>(xl, 1) * 4));
     LAY_HIP(hipMalloc((void **)&g->R2X, (uint64_t)std::max(nr, 1u) * 4));
     if (nhub) {
-        for (Buf *b : {&key, &key2, &col, &col2}) LAY_HIP(hipMalloc(&b->p, (uint64_t)nhub * 4));
+        for (Buf *b : {&key, &key2, &col, &col2}) LAY_HIP(gt_scratch_malloc(&b->p, (uint64_t)nhub * 4));
         k_hub_list<<<grid_for(nc), TPB, 0, s>>>((const uint32_t *)deg.p, (const uint32_t *)hubflag.p, (const uint32_t *)hubpos.p, nc, (uint32_t *)key.p, (uint32_t *)col.p);
         hipcub::DoubleBuffer<uint32_t> dk((uint32_t *)key.p, (uint32_t *)key2.p), dc((uint32_t *)col.p, (uint32_t *)col2.p);
         size_t tb = 0;
         LAY_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, dk, dc, nhub, 0, 32, s));   // stable: equal degrees keep ascending column order
-        Buf st; LAY_HIP(hipMalloc(&st.p, tb ? tb : 1));
+        Buf st; LAY_HIP(gt_scratch_malloc(&st.p, tb ? tb : 1));
         LAY_HIP(hipcub::DeviceRadixSort::SortPairs(st.p, tb, dk, dc, nhub, 0, 32, s));
         k_slots_hub<<<grid_for(nhub), TPB, 0, s>>>(dc.Current(), nhub, g->xslot);
         LAY_HIP(hipStreamSynchronize(s));
@@ -1342,10 +1342,10 @@ int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s)
     gt_pb *pb = g->pb;
     if (!pb || pb->nnz == 0 || pb->val_cap >= bytes_per_slot) return GT_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    if (pb->VAL) gt_scratch_free(pb->VAL);
+    if (pb->VAL) (void)hipFree(pb->VAL);   // (a long-lived buffer: not from the build's scratch pool)
     pb->VAL = nullptr; pb->val_cap = 0; pb->val_bytes = 0; pb->val_kind = 0;
     const uint64_t bytes = (uint64_t)std::max(pb->nout, 4u) * bytes_per_slot;
-    if (gt_scratch_malloc(&pb->VAL, bytes) != hipSuccess) { pb->VAL = nullptr; gt_set_error("out of device memory for the value stream (%llu bytes)", (unsigned long long)bytes); return GT_ERR_HIP; }
+    if (hipMalloc(&pb->VAL, bytes) != hipSuccess) { pb->VAL = nullptr; gt_set_error("out of device memory for the value stream (%llu bytes)", (unsigned long long)bytes); return GT_ERR_HIP; }
     GT_HIP(hipMemsetAsync(pb->VAL, 0, bytes, s));   // first touch here, not in the first SpMV
     pb->val_cap = bytes_per_slot; pb->val_allocs++;
     if (getenv("GRAPHTAP_PB_STATS")) {

@@ -86,12 +86,12 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
         assert (_gather(prs, "degree", n) == c["np1_pr20_a"]).all()
         ref = c["np1_pr20_c"]
         assert (np.abs(_gather(prs, "rank", n) - ref) / ref).max() < PR_RTOL
-        if variant != "pb_f32msg":   # converge mode: the f32-message variant's iteration count is rounding-noise dependent
-            for p, d in zip(prs, degs): p.initialize(d)
-            it, conv = _dist_execute_all(gt, dists, prs, 0)
-            assert conv and it == known_answers[name]["np1_prconv_cf"]["iterations"]
-            ref = c["np1_prconv_cf_c"]
-            assert (np.abs(_gather(prs, "rank", n) - ref) / ref).max() < PR_RTOL
+        # converge mode (the f32-message variant runs f64 messages there, gt_program_prepare: the count is the reference's)
+        for p, d in zip(prs, degs): p.initialize(d)
+        it, conv = _dist_execute_all(gt, dists, prs, 0)
+        assert conv and it == known_answers[name]["np1_prconv_cf"]["iterations"]
+        ref = c["np1_prconv_cf_c"]
+        assert (np.abs(_gather(prs, "rank", n) - ref) / ref).max() < PR_RTOL
         for p in prs + degs: p.free()
         for G in Gs: G.free()
         # BFS
@@ -102,7 +102,7 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
         for p in ps: p.root = c["root"]; p.initialize()
         for d in dists: gt._lib.check(L.gt_dist_exchange_stats(d, None, None, None, 1))
         it, conv = _dist_execute_all(gt, dists, ps, 0)
-        assert conv
+        assert conv and it == known_answers[name]["np1_bfs"]["iterations"]
         assert (_gather(ps, "parent", n) == c["np1_bfs_a"]).all() and (_gather(ps, "hops", n) == c["np1_bfs_b"]).all()
         # sparse frontier exchange (vp:970-1013): a BFS frontier is a few vertices for most of its iterations, so the ranks
         # must have shipped fewer bytes than the dense blocks hold -- unless it is switched off
@@ -131,7 +131,8 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
             G = gt.Graph(); G.load_edges(c["edges"], nv, nv, False, False, True, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
         ps = [gt.CC_Program(G, False, True, False, gt._ROW_) for G in Gs]
         for p in ps: p.initialize()
-        _dist_execute_all(gt, dists, ps, 0)
+        it, conv = _dist_execute_all(gt, dists, ps, 0)
+        assert conv and it == known_answers[name]["np1_cc"]["iterations"]
         assert (_gather(ps, "label", n) == c["np1_cc_a"]).all()
         for p in ps: p.free()
         for G in Gs: G.free()
@@ -141,12 +142,92 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
             G = gt.Graph(weighted=True); G.load_edges(c["wedges"], nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
         ps = [gt.SSSP_Program(G, False, True, False, gt._ROW_) for G in Gs]
         for p in ps: p.root = c["root"]; p.initialize()
-        _dist_execute_all(gt, dists, ps, 0)
+        it, conv = _dist_execute_all(gt, dists, ps, 0)
+        assert conv and it == known_answers[name]["np1_sssp"]["iterations"]
         assert (_gather(ps, "distance", n) == c["np1_sssp_a"]).all()
         for p in ps: p.free()
         for G in Gs: G.free()
     finally:
         for d in dists: L.gt_dist_free(d)
+
+
+def _min_apps_over_loopback(gt, c, nranks, known_answers, name):
+    """BFS, CC, SSSP of one case on `nranks` loopback ranks: labels and iteration counts against the reference's goldens;
+    returns the summed list_iterations / spmspv_iterations the ranks reported."""
+    L = gt._lib.lib()
+    nv = c["num_vertices"]; n = nv + 1
+    hs = (C.c_void_p * nranks)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, nranks))
+    dists = [C.c_void_p(hs[r]) for r in range(nranks)]
+    tot = {"list": 0, "spmspv": 0}
+
+    def run(progs):
+        out = [None] * nranks
+
+        def work(r):
+            st = gt._lib.ExecStats()
+            L.gt_set_device(0)
+            rc = L.gt_dist_execute(dists[r], progs[r]._handle(), 0, C.byref(st))
+            out[r] = (rc, L.gt_last_error().decode() if rc else "", st.iterations, st.converged, st.list_iterations, st.spmspv_iterations)
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        for r, o in enumerate(out):
+            assert o[0] == 0, "rank %d: %s" % (r, o[1])
+        assert len({o[2] for o in out}) == 1 and all(o[3] for o in out)
+        tot["list"] += sum(o[4] for o in out); tot["spmspv"] += sum(o[5] for o in out)
+        for p in progs: p._already_initialized = True
+        return out[0][2]
+    try:
+        for app, flags, weighted, fields, key in (
+                ("bfs", (False, False, False, False, False), False, (("parent", "np1_bfs_a"), ("hops", "np1_bfs_b")), "np1_bfs"),
+                ("cc", (False, False, True, False, False), False, (("label", "np1_cc_a"),), "np1_cc"),
+                ("sssp", (True, True, False, False, False), True, (("distance", "np1_sssp_a"),), "np1_sssp")):
+            Gs = []
+            for r in range(nranks):
+                G = gt.Graph(weighted=weighted)
+                G.load_edges(c["wedges"] if weighted else c["edges"], nv, nv, *flags, gt._2DT_, gt._TCSC_, rank=r, nranks=nranks); Gs.append(G)
+            cls = {"bfs": gt.BFS_Program, "cc": gt.CC_Program, "sssp": gt.SSSP_Program}[app]
+            args = {"bfs": (False, False, True), "cc": (False, True, False), "sssp": (False, True, False)}[app]
+            ps = [cls(G, *args, gt._ROW_) for G in Gs]
+            for p in ps:
+                p.root = c["root"]; p.initialize()
+            it = run(ps)
+            assert it == known_answers[name][key]["iterations"], (app, it)
+            for f, gold in fields:
+                assert (_gather(ps, f, n) == c[gold]).all(), (app, f)
+            for p in ps: p.initialize()      # a second run on the same programs and communicator
+            assert run(ps) == it
+            for f, gold in fields:
+                assert (_gather(ps, f, n) == c[gold]).all(), (app, f, "second run")
+            for p in ps: p.free()
+            for G in Gs: G.free()
+    finally:
+        for d in dists: L.gt_dist_free(d)
+    return tot
+
+
+@pytest.mark.parametrize("mode", ["by_size", "lists_forced", "lists_forced_streaming", "lists_off", "dense_protocol"])
+@pytest.mark.parametrize("nranks,slices", [(2, 1), (3, 2), (4, 4), (8, 2)])
+@pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
+def test_frontier_lists_on_several_ranks_are_bit_exact(gt, name, nranks, slices, mode, monkeypatch, known_answers):
+    """The reference's sparse path at any np (vp:711-784, 970-1013, 1475-1489): per-rank frontier lists travel as (index, value)
+    pairs, the receiving rank runs the SpMSpV straight from the pairs and applies the rows it lowered; counts ride the
+    convergence all-reduce. Labels AND iteration counts are the reference's with the path forced, forbidden and chosen by size."""
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+    if mode == "lists_forced":
+        monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "1"); monkeypatch.setenv("GRAPHTAP_SPMSPV", "1")
+    elif mode == "lists_forced_streaming":   # pairs travel, but they are scattered into x and the streaming pass runs
+        monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "1"); monkeypatch.setenv("GRAPHTAP_SPMSPV", "0")
+    elif mode == "lists_off":
+        monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "0")
+    elif mode == "dense_protocol":
+        monkeypatch.setenv("GRAPHTAP_DIST_PROTOCOL", "dense")
+    tot = _min_apps_over_loopback(gt, load_case(name), nranks, known_answers, name)
+    if mode == "lists_forced":
+        assert tot["list"] > 0 and tot["spmspv"] > 0, tot
+    if mode == "dense_protocol":
+        assert tot["list"] == 0
 
 
 def _app(app, args, env_extra):
