@@ -170,8 +170,12 @@ def main():
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     _lib.check(L.gt_set_device(local))
-    if world > 1:
+    # GRAPHTAP_FORCE_EXCHANGE=1 on one GPU: the N-rank code path (exchange layout, gt_dist_execute over RCCL at world size 1, the
+    # per-rank diagnostics below) rehearsed on a 1-GPU box
+    dist_on = world > 1 or bool(os.environ.get("GRAPHTAP_FORCE_EXCHANGE"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -225,7 +229,7 @@ def main():
         dt = time.perf_counter() - t0
         _lib.check(L.gt_graph_phase_times(G._h, C.byref(p1), C.byref(p2), C.byref(pn), 1))
         phase_ms.append([p1.value, p2.value] if pn.value else None)
-        if not G.exchange or VR.stats is not None and world > 1 and args.driver == "native" and args.backend == "nccl":
+        if not G.exchange or VR.stats is not None and dist_on and args.driver == "native" and args.backend == "nccl":
             spmv_ms, launches = VR.stats.spmv_ms, VR.stats.spmv_launches
         else:
             a, b = C.c_double(), C.c_uint32()
@@ -239,7 +243,7 @@ def main():
     i = G.info
     # B_alg = 4 nnz [IA] + 4 (nnzcols+1) [JA] + Fx nnzcols [x] + 8 nnzrows [y] of the tile-row (on several ranks x / JA
     # span the ncols_local columns the tile-row reads); Fx = bytes of a message as this variant keeps it in HBM
-    ncols = i.nnzcols if world == 1 else i.ncols_local
+    ncols = i.ncols_local if G.exchange else i.nnzcols
 
     def b_spmv_of(variant):
         fx = 4 if variant == "pb_f32msg" else 8
@@ -272,7 +276,7 @@ def main():
 
     # the all-f64 path beside it (the reference's fp is double, apps/deg.h:19): same graph, messages kept in f64
     f64_rec = None
-    if world == 1 and args.spmv == "pb_f32msg" and not args.no_f64:
+    if world == 1 and not dist_on and args.spmv == "pb_f32msg" and not args.no_f64:
         VR.free()
         _lib.check(L.gt_graph_select_spmv(G._h, _lib.GT_SPMV_PB))
         VR = gt.PR_Program(G, True, False, False, gt._ROW_)
@@ -284,7 +288,7 @@ def main():
 
     # streaming-copy ceiling of THIS box, measured live (4.7-4.8 TB/s copy against the 8 TB/s spec)
     ceiling = None
-    if world == 1:
+    if world == 1 and not dist_on:
         VR.free(); V.free(); G.free()
         n = 1 << 29
         a = torch.empty(n, dtype=torch.float32, device="cuda"); b = torch.ones(n, dtype=torch.float32, device="cuda")
@@ -303,8 +307,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(G.nnzrows_global), "nnzcols": int(i.nnzcols_global),
-                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if world > 1 else "single tile",
-                   "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if world > 1 else "C++ gt_program_execute",
+                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if dist_on else "single tile",
+                   "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if dist_on else "C++ gt_program_execute",
                    "ingress_s": round(t_ingress, 3), "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
         "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter* + k_pb_gather<double,double> (one SpMV = this launch group)",
                                                   "pb_f32msg": "k_pb_scatter* + k_pb_gather<double,float> (one SpMV = this launch group)",
@@ -317,12 +321,23 @@ def main():
     }
     if f64_rec is not None:
         out["f64_messages"] = f64_rec
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not dist_on and not args.no_cpu_baseline:
         main_b, port_b = cpu_baseline(scale, args.seed)
         out["cpu_baseline"] = main_b
         if port_b is not None:
             out["cpu_baseline_port"] = port_b
-    if world > 1:
+    if dist_on:
+        # every rank's own account of the run (C++ driver): mean per-iteration pack / exchange landing / SpMV span / apply times by
+        # HIP events, bytes it sent, how many ranks RCCL counts -- so that a scaling run explains itself
+        if args.driver == "native" and args.backend == "nccl":
+            mine = dist_native.diagnostics()
+            mine.pop("per_iteration", None)
+            mine.update(rank=rank, spmv_kernel_ms=round(float(VR.stats.spmv_ms) / max(int(VR.stats.spmv_launches), 1), 4), nnz_local=int(i.nnz_local),
+                        ncols_local=int(i.ncols_local))
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            out["per_rank"] = allr
+            out["rccl_ranks"] = mine["transport_ranks"]
         VR.free(); V.free(); G.free()
         if args.driver == "native" and args.backend == "nccl":
             dist_native.free()

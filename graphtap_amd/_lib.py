@@ -105,6 +105,8 @@ SIGNATURES = {
     "gt_dist_create_from_comm": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "gt_dist_create_loopback": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "gt_dist_free": (C.c_int, [_vp]),
+    "gt_dist_iteration_times": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "gt_dist_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gt_dist_execute": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(ExecStats)]),
     "gt_dist_all_reduce_u64": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_uint32]),
     "gt_dist_exchange_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),

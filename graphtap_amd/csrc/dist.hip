@@ -99,15 +99,35 @@ __global__ void k_block_active(const uint32_t *__restrict__ send, uint32_t n, co
         } else if (act) atomicAdd(&counts[b], 1u);
     }
 }
+// A slot of block b's pair list for every lane that wants one: ONE atomic per distinct block inside the wave (there are only K*P
+// cursors: an atomic per pair was 2 ms for a 0.5 M-vertex list and 7.9 ms for a compaction of millions). All lanes of the wave
+// must call; `want` = this lane takes a slot.
+__device__ __forceinline__ uint32_t block_slot(uint32_t *__restrict__ cursor, uint32_t b, bool want) {
+    uint32_t slot = 0;
+    uint64_t todo = __ballot(want);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (todo) {
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+        const uint32_t b0 = __shfl(b, (int)leader);
+        const uint64_t same = __ballot(want && b == b0) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[b0], (uint32_t)__popcll((unsigned long long)same));
+        base = __shfl(base, (int)leader);
+        if (want && b == b0) slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0));
+        todo &= ~same;
+    }
+    return slot;
+}
 // pairs of block b go to pairs[tab[b].start ...] (a sparse block holds at most len / 2 of them)
 __global__ void k_block_compact(const uint32_t *__restrict__ send, uint32_t n, const BlockTab *__restrict__ tab, uint32_t nb, const uint8_t *__restrict__ sparse,
                                 uint32_t *__restrict__ cursor, uint2 *__restrict__ pairs) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t v = send[i];
-        if (v == GT_INF) continue;
-        const uint32_t b = block_of(tab, nb, i);
-        if (!sparse[b]) continue;
-        pairs[tab[b].start + atomicAdd(&cursor[b], 1u)] = uint2{i - tab[b].start, v};
+    const uint32_t n64 = (n + 63) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += gridDim.x * blockDim.x) {
+        const uint32_t v = i < n ? send[i] : GT_INF;
+        uint32_t b = 0; bool want = false;
+        if (v != GT_INF) { b = block_of(tab, nb, i); want = sparse[b] != 0; }
+        const uint32_t slot = block_slot(cursor, b, want);
+        if (want) pairs[tab[b].start + slot] = uint2{i - tab[b].start, v};
     }
 }
 __global__ void k_fill_u32(uint32_t *__restrict__ p, uint32_t n, uint32_t v) {
@@ -144,14 +164,24 @@ __global__ void k_pairs_from_list(const uint32_t *__restrict__ list, const unsig
                                   uint32_t *__restrict__ cursor, uint2 *__restrict__ pairs, uint32_t *__restrict__ flag) {
     const uint32_t n = *n_dev;
     if (n > cap) { if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 1u; return; }
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t v = list[i];
-        if (!(IJ[v] & 2u)) continue;   // no column: the vertex sends nothing
-        const uint32_t c = JV[v];
-        const uint32_t m = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
-        for (uint32_t j = send_ptr[c], j1 = send_ptr[c + 1]; j < j1; j++) {
-            const uint32_t pos = send_pos[j], b = block_of(stab, nb, pos);
-            pairs[stab[b].start + atomicAdd(&cursor[b], 1u)] = uint2{pos - stab[b].start, m};
+    const uint32_t n64 = (n + 63) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += gridDim.x * blockDim.x) {
+        uint32_t j = 0, j1 = 0, m = 0;
+        if (i < n) {
+            const uint32_t v = list[i];
+            if (IJ[v] & 2u) {   // (no column: the vertex sends nothing)
+                const uint32_t c = JV[v];
+                m = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+                j = send_ptr[c]; j1 = send_ptr[c + 1];
+            }
+        }
+        while (__any(j < j1)) {   // wave-uniform rounds: the t-th destination of every lane's column
+            const bool want = j < j1;
+            uint32_t pos = 0, b = 0;
+            if (want) { pos = send_pos[j]; b = block_of(stab, nb, pos); }
+            const uint32_t slot = block_slot(cursor, b, want);
+            if (want) pairs[stab[b].start + slot] = uint2{pos - stab[b].start, m};
+            j++;
         }
     }
 }
@@ -173,15 +203,24 @@ __global__ void k_words(unsigned long long *__restrict__ w, uint32_t nwords, con
 }
 // the received pairs of all blocks -> one frontier: local column, message, entry count (ftab[b] = {first pair's output slot, pairs})
 struct FrontTab { uint32_t out0, n; };
-__global__ void k_pairs_frontier(const uint2 *__restrict__ pairs, const BlockTab *__restrict__ rtab, const FrontTab *__restrict__ ftab, uint32_t nb, uint32_t total,
-                                 const uint32_t *__restrict__ JA, uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg) {
+__global__ void __launch_bounds__(256) k_pairs_frontier(const uint2 *__restrict__ pairs, const BlockTab *__restrict__ rtab, const FrontTab *__restrict__ ftab, uint32_t nb, uint32_t total,
+                                 const uint32_t *__restrict__ JA, uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg,
+                                 unsigned long long *__restrict__ entries) {
+    unsigned long long e = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         uint32_t lo = 0, hi = nb;   // last block whose out0 <= i among those that hold pairs (empty ones share their successor's out0)
         while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (ftab[mid].out0 <= i) lo = mid; else hi = mid; }
         while (ftab[lo].n == 0 || i - ftab[lo].out0 >= ftab[lo].n) lo--;   // step back over empty blocks with the same out0
         const uint2 pv = pairs[rtab[lo].start + (i - ftab[lo].out0)];
-        const uint32_t c = rtab[lo].start + pv.x;
-        col[i] = c; val[i] = pv.y; deg[i] = JA[c + 1] - JA[c];
+        const uint32_t c = rtab[lo].start + pv.x, dg = JA[c + 1] - JA[c];
+        col[i] = c; val[i] = pv.y; deg[i] = dg; e += dg;
+    }
+    if (entries) {   // one atomic per workgroup
+        __shared__ unsigned long long part[4];
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) { e = part[0] + part[1] + part[2] + part[3]; if (e) atomicAdd(entries, e); }
     }
 }
 
@@ -245,10 +284,46 @@ struct gt_dist {
     std::vector<hipEvent_t> tev;                     // per iteration: start, messages packed, SpMV done, apply done, first slice in, last slice in
     size_t tev_used = 0;
     int rccl_ranks = 0;
+    bool timing = false; uint32_t t_iter = 0;        // events are recorded for the first GT_DIST_TIMED_ITERS iterations of a timed execute
+    std::vector<uint8_t> t_mode;                     // per timed iteration: 0 dense blocks, 1 pairs scattered into x, 2 SpMSpV from the pairs
+    std::vector<double> iter_ms;                     // [iterations][GT_DIST_TIME_FIELDS], filled when the execute ends
     uint64_t bytes_sent = 0, bytes_dense = 0, exchanges = 0;   // since the last gt_dist_exchange_stats reset (sent: to other ranks and to itself)
 };
 
 namespace {
+
+// ---- per-iteration timing (HIP events; gt_dist_iteration_times)
+constexpr uint32_t GT_DIST_TIMED_ITERS = 64, GT_DIST_TIME_FIELDS = 7, GT_DIST_TICKS = 6;
+enum { T_START = 0, T_SEND_READY = 1, T_SPMV_DONE = 2, T_APPLY_DONE = 3, T_FIRST_SLICE = 4, T_LAST_SLICE = 5 };
+int tick(gt_dist *d, int which, hipStream_t s) {
+    if (!d->timing || d->t_iter >= GT_DIST_TIMED_ITERS) return GT_OK;
+    const size_t i = (size_t)d->t_iter * GT_DIST_TICKS + which;
+    while (d->tev.size() <= i) { hipEvent_t e; GT_HIP(hipEventCreate(&e)); d->tev.push_back(e); }
+    GT_HIP(hipEventRecord(d->tev[i], s));
+    return GT_OK;
+}
+// after the run: [pack, first slice in, last slice in, SpMV (send ready -> accumulators complete, exchange waits inside), apply,
+// rest of the iteration (next messages, all-reduce, host round trip), mode]; -1 = not measured
+int collect_times(gt_dist *d, uint32_t iterations, bool comm_ticks) {
+    d->iter_ms.clear();
+    if (!d->timing) return GT_OK;
+    const uint32_t n = std::min(iterations, std::min(d->t_iter, GT_DIST_TIMED_ITERS));
+    auto ms = [&](uint32_t it, int a, uint32_t it2, int b) -> double {
+        float t = 0;
+        return hipEventElapsedTime(&t, d->tev[(size_t)it * GT_DIST_TICKS + a], d->tev[(size_t)it2 * GT_DIST_TICKS + b]) == hipSuccess ? (double)t : -1.0;
+    };
+    for (uint32_t it = 0; it < n; it++) {
+        d->iter_ms.push_back(ms(it, T_START, it, T_SEND_READY));
+        d->iter_ms.push_back(comm_ticks ? ms(it, T_SEND_READY, it, T_FIRST_SLICE) : -1.0);
+        d->iter_ms.push_back(comm_ticks ? ms(it, T_SEND_READY, it, T_LAST_SLICE) : -1.0);
+        d->iter_ms.push_back(ms(it, T_SEND_READY, it, T_SPMV_DONE));
+        d->iter_ms.push_back(ms(it, T_SPMV_DONE, it, T_APPLY_DONE));
+        d->iter_ms.push_back(it + 1 < n ? ms(it, T_APPLY_DONE, it + 1, T_START) : -1.0);
+        d->iter_ms.push_back(it < d->t_mode.size() ? (double)d->t_mode[it] : 0.0);
+    }
+    (void)hipGetLastError();
+    return GT_OK;
+}
 
 int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s) {
     if (d->loop) {
@@ -408,7 +483,7 @@ int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
 }
 
 // the K slices of one iteration's exchange are ISSUED here (all of them); consume(k) then makes `s` wait for slice k
-int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
+int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = false) {
     const gt_graph *g = p->g;
     const uint32_t K = g->info.x_slices, P = g->info.nranks, w = p->x_bytes;
     if (!d->lists_protocol) { int st = sparse_prepare(d, p, s); if (st != GT_OK) return st; }   // (the list protocol has counts and forms already)
@@ -446,9 +521,12 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
     GT_HIP(hipEventRecord(d->ev_ready, s));
     GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));   // sends read what scatter_gather packed; receives overwrite an x nobody reads any more
     while (d->ev_slice.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_slice.push_back(e); }
+    // one_round: every slice in ONE grouped round (a list iteration consumes all of them at once, and its messages are a few
+    // pairs: K rounds of ~25 us each were most of its exchange)
+    if (one_round) GT_NCCL(rccl()->GroupStart());
     for (uint32_t k = 0; k < K; k++) {
         uint64_t so = g->send_off[k], ro = g->recv_off[k];
-        GT_NCCL(rccl()->GroupStart());
+        if (!one_round) GT_NCCL(rccl()->GroupStart());
         for (uint32_t q = 0; q < P; q++) {
             const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
             const uint32_t cs = sp ? d->cnt_send[k * P + q] : 0, cr = sp ? d->cnt_recv[k * P + q] : 0;
@@ -459,8 +537,17 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s) {
             else if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
             so += ns; ro += nr;
         }
+        if (one_round) continue;
         GT_NCCL(rccl()->GroupEnd());
         GT_HIP(hipEventRecord(d->ev_slice[k], d->comm_stream));
+        if (k == 0) { int st = tick(d, T_FIRST_SLICE, d->comm_stream); if (st != GT_OK) return st; }
+        if (k + 1 == K) { int st = tick(d, T_LAST_SLICE, d->comm_stream); if (st != GT_OK) return st; }
+    }
+    if (one_round) {
+        GT_NCCL(rccl()->GroupEnd());
+        for (uint32_t k = 0; k < K; k++) GT_HIP(hipEventRecord(d->ev_slice[k], d->comm_stream));
+        int st = tick(d, T_FIRST_SLICE, d->comm_stream); if (st != GT_OK) return st;
+        st = tick(d, T_LAST_SLICE, d->comm_stream); if (st != GT_OK) return st;
     }
     return GT_OK;
 }
@@ -567,9 +654,13 @@ int dense_prepare_send(gt_dist *d, gt_program *p, hipStream_t s, bool i_need_den
     return GT_OK;
 }
 // the SpMV of a rank that received nothing but (few) pairs: the frontier is the pairs themselves
-int combine_from_pairs(gt_dist *d, gt_program *p, hipStream_t s, uint32_t total) {
+// `exact`: the entries of the frontier's columns are counted first and the SpMSpV runs only up to nnz / 32 of them (one more host
+// read -- only for frontiers of more than a few thousand columns, whose compute dwarfs it); *done = false leaves the pairs to the
+// caller, who scatters them into x for the streaming pass.
+int combine_from_pairs(gt_dist *d, gt_program *p, hipStream_t s, uint32_t total, bool exact, uint64_t max_entries, bool *done) {
     const gt_graph *g = p->g;
     const uint32_t NB = (uint32_t)d->rtab.size(), K = g->info.x_slices;
+    *done = true;
     if (!d->loop) for (uint32_t k = 0; k < K; k++) GT_HIP(hipStreamWaitEvent(s, d->ev_slice[k], 0));
     GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
     p->fl_rows_valid = true;
@@ -579,9 +670,17 @@ int combine_from_pairs(gt_dist *d, gt_program *p, hipStream_t s, uint32_t total)
     for (uint32_t b = 0; b < NB; b++) { d->h_ftab[b] = FrontTab{o, d->cnt_recv[b]}; o += d->cnt_recv[b]; }
     GT_HIP(hipMemcpyAsync(d->d_ftab, d->h_ftab.data(), NB * sizeof(FrontTab), hipMemcpyHostToDevice, s));
     if (p->fr_cap < total + 1) { int st = gt_spmspv_reserve(p, total); if (st != GT_OK) return st; }
+    if (exact) GT_HIP(hipMemsetAsync(p->d_frontier + 1, 0, sizeof(unsigned long long), s));
     k_pairs_frontier<<<(unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 4096), 256, 0, s>>>(d->pairs_recv, d->d_rtab, d->d_ftab, NB, total, g->JA,
-                                                                                                      p->fr_col, p->fr_val, p->fr_off);
+                                                                                                      p->fr_col, p->fr_val, p->fr_off, exact ? p->d_frontier + 1 : nullptr);
     GT_HIP(hipGetLastError());
+    if (exact) {
+        unsigned long long entries = 0;
+        GT_HIP(hipMemcpyAsync(&entries, p->d_frontier + 1, sizeof(entries), hipMemcpyDeviceToHost, s));
+        int st = sync_deadline(d, s, "the exchange of a list iteration"); if (st != GT_OK) return st;
+        d->round_trips++;
+        if (entries > max_entries) { *done = false; p->fl_rows_valid = false; return GT_OK; }
+    }
     d->pair_spmspv_iters++;
     return gt_spmspv_run_frontier(p, total, s);
 }
@@ -602,6 +701,7 @@ int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::
     unsigned long long local_active = 0; uint32_t my_flag = 0;
     st = all_reduce_vec(d, s, nullptr, nullptr, d->d_flag, &my_flag); if (st != GT_OK) return st;
     for (;;) {
+        st = tick(d, T_START, s); if (st != GT_OK) return st;
         if (d->h_words[1] != 0) {   // somebody's list did not fit: the dense round
             st = dense_prepare_send(d, p, s, my_flag != 0); if (st != GT_OK) return st;
             st = all_reduce_vec(d, s, nullptr, nullptr, nullptr, nullptr); if (st != GT_OK) return st;
@@ -610,18 +710,30 @@ int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::
         take_counts(d, NB);
         uint64_t total = 0; bool all_pairs = true;
         for (uint32_t b = 0; b < NB; b++) { if (d->form_recv[b]) total += d->cnt_recv[b]; else if (d->rtab[b].len) all_pairs = false; }
-        const bool from_pairs = all_pairs && spm != 0 && total < 0x7FFFFFFFull && (spm == 1 || total * 8 <= g->info.nnz_local / frac);
+        // everything arrived as pairs: the SpMSpV straight from them -- at once for a few thousand columns, after counting their
+        // entries otherwise (a frontier of hubs is the streaming pass's business: the single-rank rule, nnz / 32 entries)
+        bool from_pairs = all_pairs && spm != 0 && total < 0x7FFFFFFFull && (spm == 1 || total * 8 <= g->info.nnz_local / frac);
         if (!from_pairs) { st = fill_pair_blocks(d, p, s); if (st != GT_OK) return st; }
-        st = exchange_issue(d, p, s); if (st != GT_OK) return st;
+        st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
+        st = exchange_issue(d, p, s, from_pairs); if (st != GT_OK) return st;
         if (from_pairs) {
-            st = combine_from_pairs(d, p, s, (uint32_t)total); if (st != GT_OK) return st;
-        } else {
+            bool done = false;
+            static const uint64_t exact_from = getenv("GRAPHTAP_DIST_EXACT_FROM") ? (uint64_t)atoll(getenv("GRAPHTAP_DIST_EXACT_FROM")) : 4096;   // pairs above which the entries are counted first
+            static const uint64_t max_entries_env = getenv("GRAPHTAP_DIST_MAX_ENTRIES") ? (uint64_t)atoll(getenv("GRAPHTAP_DIST_MAX_ENTRIES")) : ~0ull;   // (tests: force the fallback)
+            st = combine_from_pairs(d, p, s, (uint32_t)total, spm != 1 && total > exact_from, std::min<uint64_t>(g->info.nnz_local / frac, max_entries_env), &done); if (st != GT_OK) return st;
+            if (!done) { from_pairs = false; st = fill_pair_blocks(d, p, s); if (st != GT_OK) return st; }
+        }
+        if (d->timing && d->t_iter < GT_DIST_TIMED_ITERS) { d->t_mode.resize(d->t_iter + 1); d->t_mode[d->t_iter] = from_pairs ? 2 : (my_flag == 0 ? 1 : 0); }
+        if (!from_pairs) {
             for (uint32_t k = 0; k < K; k++) {
                 st = exchange_consume(d, p, k, s); if (st != GT_OK) return st;
                 st = (K > 1) ? gt_program_combine_slice(p, k) : gt_program_combine(p); if (st != GT_OK) return st;
             }
         }
+        st = tick(d, T_SPMV_DONE, s); if (st != GT_OK) return st;
         st = gt_program_apply_begin(p, 0); if (st != GT_OK) return st;
+        st = tick(d, T_APPLY_DONE, s); if (st != GT_OK) return st;
+        d->t_iter++;
         st = lists_prepare_send(d, p, s, p->d_active); if (st != GT_OK) return st;
         st = all_reduce_vec(d, s, p->d_active, &local_active, d->d_flag, &my_flag); if (st != GT_OK) return st;   // the host round trip of the iteration
         st = gt_program_apply_end(p, local_active); if (st != GT_OK) return st;
@@ -742,6 +854,22 @@ int gt_dist_exchange_stats(gt_dist *d, uint64_t *bytes_sent, uint64_t *bytes_den
     return GT_OK;
 }
 
+int gt_dist_iteration_times(gt_dist *d, double *out, uint32_t max_iterations, uint32_t *iterations) {
+    GT_REQUIRE(d && iterations, GT_ERR_INVALID, "null argument");
+    const uint32_t n = (uint32_t)(d->iter_ms.size() / GT_DIST_TIME_FIELDS);
+    *iterations = n;
+    if (out) memcpy(out, d->iter_ms.data(), (size_t)std::min(n, max_iterations) * GT_DIST_TIME_FIELDS * sizeof(double));
+    return GT_OK;
+}
+int gt_dist_info(gt_dist *d, int32_t *transport_ranks, uint64_t *list_iterations, uint64_t *pair_spmspv_iterations, uint64_t *host_round_trips) {
+    GT_REQUIRE(d, GT_ERR_INVALID, "null argument");
+    if (transport_ranks) *transport_ranks = d->loop ? d->loop->n : d->rccl_ranks;
+    if (list_iterations) *list_iterations = d->list_iters;
+    if (pair_spmspv_iterations) *pair_spmspv_iterations = d->pair_spmspv_iters;
+    if (host_round_trips) *host_round_trips = d->round_trips;
+    return GT_OK;
+}
+
 int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count) {
     GT_REQUIRE(d && host_values, GT_ERR_INVALID, "null argument");
     return dist_all_reduce_words(d, host_values, count, d->comm_stream);
@@ -762,6 +890,9 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     d->sp_graph = nullptr;   // block tables of the sparse exchange: rebuilt per call (a freed graph's address may come back)
     if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
     (void)gt_program_enable_timing(p, stats != nullptr);
+    d->timing = stats != nullptr; d->t_iter = 0; d->t_mode.clear();
+    d->list_iters = d->pair_spmspv_iters = d->round_trips = 0;
+    if (!d->loop && rccl()->CommCount && d->comm) (void)rccl()->CommCount(d->comm, &d->rccl_ranks);
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
     k_dist_preload<<<1, 64, 0, s>>>();   // this file's code object is loaded at its first launch (milliseconds): not inside the timed loop
     GT_HIP(hipStreamSynchronize(s));
@@ -771,8 +902,10 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     const bool lists = check && !col && !p->stationary && p->fl_enabled && !(penv && strcmp(penv, "dense") == 0) && !(sxenv && atoi(sxenv) == 0);
     if (lists) { int st = lists_execute(d, p, stats, t0); if (st != GT_OK) { d->lists_protocol = false; d->sparse_now = false; return st; } }
     else for (;;) {
-        int st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        int st = tick(d, T_START, s); if (st != GT_OK) return st;
+        st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
         if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; }
+        st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
         if (!col && !p->converged) {
             st = exchange_issue(d, p, s); if (st != GT_OK) return st;
             for (uint32_t k = 0; k < K; k++) {
@@ -783,15 +916,21 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
             st = gt_program_combine(p); if (st != GT_OK) return st;
         }
         if (col && !p->converged) { st = all_reduce_y(d, p, s); if (st != GT_OK) return st; }
+        st = tick(d, T_SPMV_DONE, s); if (st != GT_OK) return st;
         uint64_t active = 0;
         st = gt_program_apply(p, iters, check ? &active : nullptr); if (st != GT_OK) return st;
+        st = tick(d, T_APPLY_DONE, s); if (st != GT_OK) return st;
+        d->t_iter++;
         if (check) {
+            d->round_trips += 2;   // the count read by apply, then the all-reduce (+ the sparse exchange's own, sparse_prepare)
             st = dist_all_reduce_words(d, &active, 1, s); if (st != GT_OK) return st;       // has_converged, vp:1918
             p->last_active = active;
             if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
         } else if (p->iteration >= iters) break;
     }
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = sync_deadline(d, s, "the iteration loop"); if (st != GT_OK) return st; }
+    if (d->comm_stream) { int st = sync_deadline(d, d->comm_stream, "the exchange"); if (st != GT_OK) return st; }
+    { int st = collect_times(d, p->iteration, !d->loop && !col); if (st != GT_OK) return st; }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->iterations = p->iteration; stats->converged = p->converged;

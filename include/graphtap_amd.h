@@ -337,6 +337,17 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
  * messages (!= infinity()) are fewer than half of its elements as (index, value) pairs -- the reference's sparse broadcast,
  * vp:970-1013 with the count header of vp:766-773 -- after a count exchange; GRAPHTAP_SPARSE_EXCHANGE=0 keeps every block dense. */
 int gt_dist_exchange_stats(gt_dist *d, uint64_t *bytes_sent, uint64_t *bytes_dense, uint64_t *exchanges, int reset);
+/* Diagnostics of the last gt_dist_execute that was given a stats pointer. Per iteration (the first 64), in milliseconds by HIP events:
+ * [0] messages written and packed, [1] first slice of the exchange landed / [2] last slice landed (after the send buffer was ready;
+ * RCCL transport only, -1 otherwise), [3] SpMV span (send buffer ready -> accumulators complete: exchange waits that were not
+ * hidden are inside), [4] apply, [5] rest of the iteration (next messages, the all-reduce, the host round trip; converge mode),
+ * [6] mode: 0 dense blocks, 1 pairs scattered into x, 2 SpMSpV straight from the pairs. `out` holds 7 doubles per iteration. */
+int gt_dist_iteration_times(gt_dist *d, double *out, uint32_t max_iterations, uint32_t *iterations);
+/* Ranks of the transport (ncclCommCount for RCCL; the loopback context's size), and counters of the last converge-mode run of a min
+ * program: iterations in which every rank's frontier travelled as a list, iterations this rank ran the SpMSpV straight from the
+ * pairs, host round trips (one per iteration while the frontiers are lists). Any pointer may be null. */
+int gt_dist_info(gt_dist *d, int32_t *transport_ranks, uint64_t *list_iterations, uint64_t *pair_spmspv_iterations, uint64_t *host_round_trips);
+
 /* sum over ranks of `count` (<= 64) host words, in place: checksum() (vp:1940, 1956), nnz_global, display() */
 int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count);
 

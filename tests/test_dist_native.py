@@ -207,7 +207,7 @@ def _min_apps_over_loopback(gt, c, nranks, known_answers, name):
     return tot
 
 
-@pytest.mark.parametrize("mode", ["by_size", "lists_forced", "lists_forced_streaming", "lists_off", "dense_protocol"])
+@pytest.mark.parametrize("mode", ["by_size", "lists_forced", "lists_forced_streaming", "lists_counted_then_streamed", "lists_off", "dense_protocol"])
 @pytest.mark.parametrize("nranks,slices", [(2, 1), (3, 2), (4, 4), (8, 2)])
 @pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12"])
 def test_frontier_lists_on_several_ranks_are_bit_exact(gt, name, nranks, slices, mode, monkeypatch, known_answers):
@@ -219,6 +219,9 @@ def test_frontier_lists_on_several_ranks_are_bit_exact(gt, name, nranks, slices,
         monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "1"); monkeypatch.setenv("GRAPHTAP_SPMSPV", "1")
     elif mode == "lists_forced_streaming":   # pairs travel, but they are scattered into x and the streaming pass runs
         monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "1"); monkeypatch.setenv("GRAPHTAP_SPMSPV", "0")
+    elif mode == "lists_counted_then_streamed":   # the pairs' entries are counted, found too many, and the pairs go through x after all
+        monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "1"); monkeypatch.setenv("GRAPHTAP_SPMSPV_FRACTION", "1")
+        monkeypatch.setenv("GRAPHTAP_DIST_EXACT_FROM", "0"); monkeypatch.setenv("GRAPHTAP_DIST_MAX_ENTRIES", "3")
     elif mode == "lists_off":
         monkeypatch.setenv("GRAPHTAP_DIST_LISTS", "0")
     elif mode == "dense_protocol":
