@@ -508,10 +508,19 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     const unsigned grid = (unsigned)std::min<uint64_t>((nact + TPB - 1) / TPB, 4096);
     k_list_frontier<<<grid, TPB, 0, s>>>(p->fl_v[p->fl_cur], nact, g->IJ, g->JV, g->JA, p->s0, g->info.rank * g->info.tile_height, gt_vidmap_of(g),
                                          p->prm.kind, p->fr_col, p->fr_val, p->fr_off, p->d_frontier);
+    GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
+    // a few thousand columns: no need to know their entries first (even if they were all hubs the entry-parallel kernel takes
+    // them in a fraction of a streaming pass) -- the count costs a host round trip, a quarter of such an iteration
+    static const uint32_t count_from = getenv("GRAPHTAP_SPMSPV_COUNT_FROM") ? (uint32_t)atoi(getenv("GRAPHTAP_SPMSPV_COUNT_FROM")) : 4096;
+    if (nact <= count_from) {
+        int st = gt_spmspv_run_frontier(p, nact, s);
+        if (st != GT_OK) return st;
+        *done = true;
+        return GT_OK;
+    }
     unsigned long long h[2] = {0, 0};
     GT_HIP(hipMemcpyAsync(h, p->d_frontier, sizeof(h), hipMemcpyDeviceToHost, s));
     GT_HIP(hipStreamSynchronize(s));
-    GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
     if (h[1] == 0) { *done = true; p->fl_rows_valid = true; return GT_OK; }
     // From the list, with eight lanes per column, the sparse pass wins up to ~nnz/32 entries (tools/spmspv_sweep.sh on R-MAT-26:
     // 10 M entries of 1.27 M columns 0.41 against 1.49 ms, 4.7 M of 3.7 M columns 0.41 against 0.95 ms, but 102 M entries of

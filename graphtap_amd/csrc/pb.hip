@@ -27,7 +27,7 @@
 // the dummy accumulator row R), so quads never straddle runs and every access is aligned.
 // Static per-graph data, built once on the device (rocPRIM sorts / scans):
 //   LCOL[v]  u16  v-order = runs sorted by (chunk, bin), entries inside by (row, col); bits 0-13: slot - window start
-//                 (8192 = pad, dense), bit 14: last entry of its (256-entry group, row) stretch (dense), bit 15: first
+//                 (W = pad, dense), bit 15: last entry of its (256-entry group, row) stretch (dense), bit 14: first
 //                 entry of a run
 //   LROW[k]  u16  k-order = outputs, runs sorted by (bin, chunk); row & (R-1), R for a pad
 //   WT[v]    u8 / u16 / u32 (the narrowest the largest weight fits) weights in v-order (min-plus only)
@@ -81,9 +81,11 @@ constexpr int P2_U = GT_P2_U;            // quads in flight per lane in phase 2
 // and without a limit; with the hubs-first layout the dense windows hold 4+ entries per (window, row) pair and only whole
 // groups collect them.
 constexpr uint32_t AGG_MASK = 255;
-constexpr uint16_t HEAD = 0x8000;
+// flag bits of an LCOL entry. GEND sits in the SIGN bit of the 16-bit word: phase 1 tests it four times per quad, and a sign test of
+// either half of a dword is one compare (v_cmp_gt_i16 / v_cmp_gt_i32), a test of any other bit two instructions
+constexpr uint16_t GEND = 0x8000;      // dense: last entry of its (group, row) stretch
 constexpr uint16_t COLMASK = 0x3FFF;
-constexpr uint16_t GEND = 0x4000;      // dense: last entry of its (group, row) stretch
+constexpr uint16_t HEAD = 0x4000;      // first entry of a run (entry 0 of a quad only)
 constexpr uint16_t PADCOL = W;         // dense: LDS slot W holds the semiring's neutral message
 constexpr int TPB = 256;
 
@@ -594,34 +596,33 @@ template <int CTRL, int ROW_MASK, class TV> __device__ __forceinline__ TV dpp_ge
         return (TV)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROW_MASK, 0xf, false);
     }
 }
-// inclusive prefix sum of a small count over the wave
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
-    x += dpp_get<0x111, 0xf, uint32_t>(x, 0u);
-    x += dpp_get<0x112, 0xf, uint32_t>(x, 0u);
-    x += dpp_get<0x114, 0xf, uint32_t>(x, 0u);
-    x += dpp_get<0x118, 0xf, uint32_t>(x, 0u);
-    x += dpp_get<0x142, 0xa, uint32_t>(x, 0u);
-    x += dpp_get<0x143, 0xc, uint32_t>(x, 0u);
-    return x;
-}
-// Segmented EXCLUSIVE scan: lane L gets the combination of t over the lanes below it back to (and including) the nearest
-// lane whose flag is set -- what the quads before it leave open of the output stretch that is running when lane L begins.
-template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry(TV t, bool flag) {
+// Segmented EXCLUSIVE scan over the wave: lane L gets the combination of t over the lanes below it back to (and including) the
+// nearest lane whose flag is set -- what the quads before it leave open of the output stretch that is running when lane L
+// begins. The flags are ONE wave-uniform 64-bit mask (F: lanes that hold an end): the flag half of the scan runs on the scalar
+// unit (a shift, an AND with the row pattern and an OR per step) and a step costs two vector instructions -- the DPP combine and
+// a select on ~F through an SGPR pair. (With per-lane flags a step was five: two DPP moves, compare, select, OR; phase 1 is
+// bound by instruction issue: 526 M vector instructions per SpMV of R-MAT-26 = 0.86 ms of its 0.93, profiles/r03/.)
+template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry_masked(TV t, uint64_t F) {
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
-    uint32_t f = flag ? 1u : 0u;
     TV v = t;
-#define GT_SEG_STEP(CTRL, RM)                                                      \
+#define GT_MSEG_STEP(CTRL, RM, NEXT_F)                                             \
     {                                                                              \
         const TV vs = dpp_get<CTRL, RM, TV>(v, neutral);                           \
-        const uint32_t fs = dpp_get<CTRL, RM, uint32_t>(f, 0u);                    \
-        v = f ? v : comb(v, vs);                                                   \
-        f |= fs;                                                                   \
+        v = __builtin_amdgcn_inverse_ballot_w64(~F) ? comb(v, vs) : v;             \
+        F |= (NEXT_F);                                                             \
     }
-    GT_SEG_STEP(0x111, 0xf) GT_SEG_STEP(0x112, 0xf) GT_SEG_STEP(0x114, 0xf) GT_SEG_STEP(0x118, 0xf)
-    GT_SEG_STEP(0x142, 0xa) GT_SEG_STEP(0x143, 0xc)
-#undef GT_SEG_STEP
+    GT_MSEG_STEP(0x111, 0xf, (F << 1) & 0xFFFEFFFEFFFEFFFEull)   // row_shr:1 .. 8: lane l takes lane l - d of its row of 16
+    GT_MSEG_STEP(0x112, 0xf, (F << 2) & 0xFFFCFFFCFFFCFFFCull)
+    GT_MSEG_STEP(0x114, 0xf, (F << 4) & 0xFFF0FFF0FFF0FFF0ull)
+    GT_MSEG_STEP(0x118, 0xf, (F << 8) & 0xFF00FF00FF00FF00ull)
+    GT_MSEG_STEP(0x142, 0xa, (((F >> 15) & 1ull) ? 0x00000000FFFF0000ull : 0ull) | (((F >> 47) & 1ull) ? 0xFFFF000000000000ull : 0ull))   // row_bcast:15 into rows 1, 3
+    GT_MSEG_STEP(0x143, 0xc, 0ull)                                // row_bcast:31 into rows 2, 3 (the flags are not needed afterwards)
+#undef GT_MSEG_STEP
     return dpp_get<0x138, 0xf, TV>(v, neutral);   // wave_shr:1: the inclusive result of the lane below
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m, uint32_t acc) {   // acc + the set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc));
 }
 
 // ---- dense windows: pre-aggregation over whole 256-entry groups
@@ -693,14 +694,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                 st_stream(reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)), o);   // runs start at multiples of four slots in both orders
                 continue;
             }
-            // output-end bits of the quad
+            // output-end bits of the quad, as four wave-uniform masks
             const bool e0 = (lc[u].c[0] & GEND) != 0, e1 = (lc[u].c[1] & GEND) != 0, e2 = (lc[u].c[2] & GEND) != 0, e3 = (lc[u].c[3] & GEND) != 0;
-            const uint32_t n0 = e0 ? 1u : 0u, n1 = n0 + (e1 ? 1u : 0u), n2 = n1 + (e2 ? 1u : 0u), nend = n2 + (e3 ? 1u : 0u);
-            const bool has_end = nend != 0;
-            // k-slot of the quad's first output: outputs of the lanes below + the constant of the lane's run
+            const uint64_t E0 = __ballot(e0), E1 = __ballot(e1), E2 = __ballot(e2), E3 = __ballot(e3);
+            const uint32_t n0 = e0 ? 1u : 0u, n1 = n0 + (e1 ? 1u : 0u), n2 = n1 + (e2 ? 1u : 0u);
+            // dense index of the quad's first output inside the group = the ends in the lanes below (four mbcnt pairs; the DPP prefix
+            // scan of the per-lane counts was twenty instructions)
+            const uint32_t i0 = lanes_below(E3, lanes_below(E2, lanes_below(E1, lanes_below(E0, 0u))));
             const bool head = lane != 0 && (lc[u].c[0] & HEAD) != 0;
-            const uint32_t sc = wave_scan_add(nend), i0 = sc - nend;   // dense index of the quad's first output inside the group
-            const uint32_t delta = run_delta(lane, head, gw[u], KSTART);
             const TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
                      v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
@@ -709,10 +710,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const TV a2 = e1 ? v2 : comb(a1, v2);
             const TV a3 = e2 ? v3 : comb(a2, v3);
             // what the quad leaves open for the lanes above: everything when it holds no end, else what follows its last end
-            const TV carry = wave_carry<TV, IS_MIN>(e3 ? neutral : a3, has_end);
+            const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
             // the quad's first end also closes what the lanes below left open
             if constexpr (!STAGED) {   // every lane stores its outputs itself: the k-slots of a wave's outputs are consecutive
-                const uint32_t k0 = i0 + delta;
+                const uint32_t k0 = i0 + run_delta(lane, head, gw[u], KSTART);   // + the constant of the lane's run
                 if (e0) st_stream(reinterpret_cast<TV *>(VALb + (size_t)(k0 * (uint32_t)sizeof(TV))), comb(carry, v0));
                 if (e1) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n0) * (uint32_t)sizeof(TV))), n0 ? a1 : comb(carry, a1));
                 if (e2) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n1) * (uint32_t)sizeof(TV))), n1 ? a2 : comb(carry, a2));
@@ -724,15 +725,21 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             if (e1) st[i0 + n0] = n0 ? a1 : comb(carry, a1);
             if (e2) st[i0 + n1] = n1 ? a2 : comb(carry, a2);
             if (e3) st[i0 + n2] = n2 ? a3 : comb(carry, a3);
-            // out: output i of the group goes to k-slot i + (the constant of its run); 64 consecutive outputs per store
-            const uint32_t nout = __builtin_amdgcn_readlane(sc, 63);
-            const uint32_t d0 = __builtin_amdgcn_readlane(delta, 0);
+            // out: output i of the group goes to k-slot i + (the constant of its run); 64 consecutive outputs per store. The
+            // constants come off the group record with scalar reads: dword 0 for the run the group starts in, dword j for the run
+            // of its j-th head (lane j of gw holds dword j), KSTART for heads beyond the sixth.
+            const uint32_t nout = (uint32_t)(__popcll((unsigned long long)E0) + __popcll((unsigned long long)E1) + __popcll((unsigned long long)E2) + __popcll((unsigned long long)E3));
+            const uint32_t d0 = __builtin_amdgcn_readlane(gw[u], 0);
             const uint64_t Hb = __ballot(head);
             for (uint32_t i = lane; i < nout; i += 64) {
-                uint32_t d = d0;
+                uint32_t d = d0, j = 0;
                 for (uint64_t Hm = Hb; Hm; Hm &= Hm - 1) {
                     const uint32_t hl = (uint32_t)__ffsll((unsigned long long)Hm) - 1;
-                    const uint32_t S = __builtin_amdgcn_readlane(i0, hl), D = __builtin_amdgcn_readlane(delta, hl);
+                    j++;
+                    const uint32_t S = __builtin_amdgcn_readlane(i0, hl);
+                    uint32_t D;
+                    if (j < 7) D = __builtin_amdgcn_readlane(gw[u], j);
+                    else { const uint32_t s0r = __builtin_amdgcn_readlane(gw[u], 7); D = KSTART[s0r + j] + (d0 - KSTART[s0r]); }   // delta(run s) = KSTART[s] + X[group start]
                     d = i >= S ? D : d;
                 }
                 st_stream(reinterpret_cast<TV *>(VALb + (size_t)((i + d) * (uint32_t)sizeof(TV))), (TV)st[i]);
