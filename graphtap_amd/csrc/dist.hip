@@ -251,7 +251,7 @@ struct gt_dist {
     bool own_comm = false;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr;
-    std::vector<hipEvent_t> ev_slice;
+    std::vector<hipEvent_t> ev_slice, ev_pack;
     uint64_t *d_word = nullptr;     // device staging of the small all-reduces
     // loopback
     std::shared_ptr<LoopCtx> loop;
@@ -521,11 +521,15 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = fa
     GT_HIP(hipEventRecord(d->ev_ready, s));
     GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));   // sends read what scatter_gather packed; receives overwrite an x nobody reads any more
     while (d->ev_slice.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_slice.push_back(e); }
+    while (d->ev_pack.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_pack.push_back(e); }
+    if (p->pack_deferred)   // slice by slice: the sends of slice k start when ITS packing is done (k_pack_send of a tile-row of 8 is 0.07 ms)
+        for (uint32_t k = 0; k < K; k++) { int st = gt_program_pack_slice(p, k); if (st != GT_OK) return st; GT_HIP(hipEventRecord(d->ev_pack[k], s)); }
     // one_round: every slice in ONE grouped round (a list iteration consumes all of them at once, and its messages are a few
     // pairs: K rounds of ~25 us each were most of its exchange)
     if (one_round) GT_NCCL(rccl()->GroupStart());
     for (uint32_t k = 0; k < K; k++) {
         uint64_t so = g->send_off[k], ro = g->recv_off[k];
+        if (p->pack_deferred) GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_pack[k], 0));
         if (!one_round) GT_NCCL(rccl()->GroupStart());
         for (uint32_t q = 0; q < P; q++) {
             const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
@@ -835,6 +839,7 @@ int gt_dist_free(gt_dist *d) {
     if (d->comm && d->own_comm && rccl()) (void)rccl()->CommDestroy(d->comm);
     if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
     for (hipEvent_t e : d->ev_slice) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->ev_pack) (void)hipEventDestroy(e);
     if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     if (d->d_word) (void)hipFree(d->d_word);
     if (d->tmp) (void)hipFree(d->tmp);
@@ -903,16 +908,18 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     if (lists) { int st = lists_execute(d, p, stats, t0); if (st != GT_OK) { d->lists_protocol = false; d->sparse_now = false; return st; } }
     else for (;;) {
         int st = tick(d, T_START, s); if (st != GT_OK) return st;
-        st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+        p->pack_deferred = !d->loop && !col && p->stationary && K > 1;   // stationary programs send dense blocks: packing and sending overlap slice by slice
+        st = gt_program_scatter_gather(p); if (st != GT_OK) { p->pack_deferred = false; return st; }
         if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; }
         st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
         if (!col && !p->converged) {
-            st = exchange_issue(d, p, s); if (st != GT_OK) return st;
+            st = exchange_issue(d, p, s); p->pack_deferred = false; if (st != GT_OK) return st;
             for (uint32_t k = 0; k < K; k++) {
                 st = exchange_consume(d, p, k, s); if (st != GT_OK) return st;
                 st = (K > 1) ? gt_program_combine_slice(p, k) : gt_program_combine(p); if (st != GT_OK) return st;
             }
         } else {
+            p->pack_deferred = false;
             st = gt_program_combine(p); if (st != GT_OK) return st;
         }
         if (col && !p->converged) { st = all_reduce_y(d, p, s); if (st != GT_OK) return st; }

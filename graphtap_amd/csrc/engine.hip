@@ -783,10 +783,21 @@ int gt_program_scatter_gather(gt_program *p) {
             if (!p->x_deferred) { int st = gt_min_messenger(p); if (st != GT_OK) return st; }
             break;
     }
-    if (p->xseg && g->send_elems) {
+    if (p->xseg && g->send_elems && !p->pack_deferred) {   // (deferred: the driver packs slice by slice, gt_program_pack_slice)
         if (p->x_bytes == 8) k_pack_send<uint64_t><<<grid_for(g->send_elems), TPB, 0, s>>>((const uint64_t *)p->xseg, g->send_idx, g->send_elems, (uint64_t *)p->send);
         else k_pack_send<uint32_t><<<grid_for(g->send_elems), TPB, 0, s>>>((const uint32_t *)p->xseg, g->send_idx, g->send_elems, (uint32_t *)p->send);
     }
+    GT_HIP(hipGetLastError());
+    return GT_OK;
+}
+// the per-destination packing of slice k alone: the C++ driver sends slice k while slice k+1 is still being packed
+int gt_program_pack_slice(gt_program *p, uint32_t k) {
+    const gt_graph *g = p->g;
+    if (!p->xseg || k >= g->info.x_slices) return GT_OK;
+    const uint64_t lo = g->send_off[k], n = g->send_off[k + 1] - lo;
+    if (!n) return GT_OK;
+    if (p->x_bytes == 8) k_pack_send<uint64_t><<<grid_for(n), TPB, 0, p->stream>>>((const uint64_t *)p->xseg, g->send_idx + lo, n, (uint64_t *)p->send + lo);
+    else k_pack_send<uint32_t><<<grid_for(n), TPB, 0, p->stream>>>((const uint32_t *)p->xseg, g->send_idx + lo, n, (uint32_t *)p->send + lo);
     GT_HIP(hipGetLastError());
     return GT_OK;
 }

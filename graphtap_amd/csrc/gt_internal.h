@@ -197,6 +197,7 @@ struct gt_program {
     // a bottom-up step reads no messages: scatter_gather() defers the messenger when such a step is likely, combine runs it
     // after all if the step is declined, and x is marked stale (the next messenger rewrites all of it) if it was not needed
     bool x_deferred = false, x_stale = false;
+    bool pack_deferred = false;   // scatter_gather leaves the per-destination packing to gt_program_pack_slice (the C++ multi-rank driver)
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
     bool cf_hint = false;
@@ -280,6 +281,7 @@ int gt_spmspv_reserve(gt_program *p, uint32_t nact);
 // pairs its peers sent, dist.hip): y lowered with atomics, the rows it lowered left in fl_rows for the row-list apply
 int gt_spmspv_run_frontier(gt_program *p, uint32_t nact, hipStream_t s);
 // apply() in two halves for a driver that reads the active count itself, together with other words (dist.hip)
+extern "C" int gt_program_pack_slice(gt_program *p, uint32_t k);
 extern "C" int gt_program_apply_begin(gt_program *p, uint32_t num_iterations);
 extern "C" int gt_program_apply_end(gt_program *p, uint64_t active_local);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
