@@ -646,7 +646,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // this row and storing 64 consecutive slots per instruction gave 8 % (1.69 -> 1.55 ms per SpMV)
     // The min programs keep the direct stores: the staged form is 10-20 % SLOWER for them (CC R-MAT-26: 3.39 -> 4.06 ms for a
     // full pass), measured by A/B on one box; neither occupancy nor the number of run heads explains it.
-    constexpr bool STAGED = !IS_MIN;
+#ifndef GT_P1_STAGE_MIN
+#define GT_P1_STAGE_MIN 0
+#endif
+    constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
     __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 1];
     const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)

@@ -971,3 +971,24 @@ def test_multirank_tile_rows_are_balanced(gt):
     assert max(rows) < 1.1 * (sum(rows) / p) and max(cols) < 1.1 * (sum(cols) / p)
     allv = np.concatenate(allv)
     assert allv.size == (1 << scale) + 1 and np.unique(allv).size == allv.size   # every vertex owned exactly once
+
+
+def test_no_device_allocation_inside_the_iteration_loop(gt):
+    """initialize() reserves everything execute() needs -- the value stream of the SpMV (gt_pb_reserve_val; for PageRank at both
+    message widths), the frontier buffers, the timing events: gt_exec_stats.allocs_in_execute stays 0 for all five programs,
+    first execute included (round 2's first-process stall was the value stream allocated inside iteration 1's combine)."""
+    c = load_case("rmat12"); nv = c["num_vertices"]
+    G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1); assert V.stats.allocs_in_execute == 0
+    P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(20); assert P.stats.allocs_in_execute == 0
+    P.initialize(V); P.execute(); assert P.stats.allocs_in_execute == 0
+    P.free(); V.free(); G.free()
+    for app in ("bfs", "cc", "sssp"):
+        weighted = app == "sssp"
+        G = gt.Graph(weighted=weighted)
+        flags = {"bfs": (False, False, False, False, False), "cc": (False, False, True, False, False), "sssp": (True, True, False, False, False)}[app]
+        G.load_edges(c["wedges"] if weighted else c["edges"], nv, nv, *flags, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = {"bfs": gt.BFS_Program, "cc": gt.CC_Program, "sssp": gt.SSSP_Program}[app](G, False, app != "bfs", app == "bfs", gt._ROW_)
+        P.root = c["root"]; P.execute(); assert P.stats.allocs_in_execute == 0, app
+        P.initialize(); P.execute(); assert P.stats.allocs_in_execute == 0, app
+        P.free(); G.free()
