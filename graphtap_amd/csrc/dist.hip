@@ -67,6 +67,8 @@ Rccl *rccl() {
     });
     return r.lib ? &r : nullptr;
 }
+#define GT_LOOP_BARRIER(c)                                                                                      \
+    do { if (!(c).barrier()) { gt_set_error("a peer rank of this loopback group failed"); return GT_ERR_STATE; } } while (0)
 #define GT_NCCL(call)                                                                                          \
     do {                                                                                                       \
         ncclResult_t r_ = (call);                                                                              \
@@ -234,12 +236,16 @@ struct LoopCtx {
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<LoopPeer> peer;
-    void barrier() {
+    bool aborted = false;   // a rank left gt_dist_execute with an error: nobody waits for it any more
+    bool barrier() {   // false: a peer failed, the caller gives up too
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const uint64_t gen = generation;
         if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else cv.wait(lk, [&] { return generation != gen || aborted; });
+        return !aborted;
     }
+    void abort() { std::unique_lock<std::mutex> lk(mu); aborted = true; arrived = 0; generation++; cv.notify_all(); }
 };
 
 }  // namespace
@@ -330,10 +336,10 @@ int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s
         LoopCtx &c = *d->loop;
         for (uint32_t i = 0; i < count; i++) {     // one word at a time: this is test plumbing
             c.peer[d->rank].word = v[i];
-            c.barrier();
+            GT_LOOP_BARRIER(c);
             uint64_t sum = 0;
             for (int r = 0; r < c.n; r++) sum += c.peer[r].word;
-            c.barrier();
+            GT_LOOP_BARRIER(c);
             v[i] = sum;
         }
         return GT_OK;
@@ -450,9 +456,9 @@ int sparse_prepare(gt_dist *d, gt_program *p, hipStream_t s) {
     if (d->loop) {
         LoopCtx &c = *d->loop;
         c.peer[d->rank].counts = d->cnt_send.data();
-        c.barrier();
+        GT_LOOP_BARRIER(c);
         for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) d->cnt_recv[k * P + q] = c.peer[q].counts[k * P + d->rank];
-        c.barrier();
+        GT_LOOP_BARRIER(c);
     } else {
         std::vector<uint32_t> out(NB), in(NB);   // [peer][slice]
         for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) out[q * K + k] = d->cnt_send[k * P + q];
@@ -493,7 +499,7 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = fa
         LoopCtx &c = *d->loop;
         c.peer[d->rank].pairs = d->pairs_send;
         GT_HIP(hipStreamSynchronize(s));                      // my send buffer is packed
-        c.barrier();
+        GT_LOOP_BARRIER(c);
         for (uint32_t k = 0; k < K; k++) {
             uint64_t dst = g->recv_off[k];
             for (uint32_t src = 0; src < P; src++) {
@@ -514,7 +520,7 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = fa
             d->bytes_dense += (uint64_t)len * w; d->bytes_sent += (sp && d->form_send[b]) ? (uint64_t)cnt * 8 : (uint64_t)len * w;
         }
         GT_HIP(hipStreamSynchronize(s));
-        c.barrier();                                          // every rank has read every send buffer
+        GT_LOOP_BARRIER(c);                                          // every rank has read every send buffer
         return GT_OK;
     }
     const ncclDataType_t ty = (w == 8) ? ncclUint64 : ncclUint32;
@@ -587,9 +593,9 @@ int all_reduce_vec(gt_dist *d, hipStream_t s, const unsigned long long *extra_de
         GT_HIP(hipMemcpyAsync(mine.data(), d->d_words, (size_t)d->nwords * 8, hipMemcpyDeviceToHost, s));
         GT_HIP(hipStreamSynchronize(s));
         c.peer[d->rank].words = mine.data();
-        c.barrier();
+        GT_LOOP_BARRIER(c);
         for (uint32_t i = 0; i < d->nwords; i++) { unsigned long long t = 0; for (int r = 0; r < c.n; r++) t += c.peer[r].words[i]; d->h_words[i] = t; }
-        c.barrier();
+        GT_LOOP_BARRIER(c);
         return GT_OK;
     }
     GT_NCCL(rccl()->AllReduce(d->d_words, d->d_words, d->nwords, ncclUint64, ncclSum, d->comm, s));
@@ -760,11 +766,11 @@ int all_reduce_y(gt_dist *d, gt_program *p, hipStream_t s) {
         }
         GT_HIP(hipStreamSynchronize(s));
         c.peer[d->rank].y = (const uint32_t *)p->y;
-        c.barrier();
+        GT_LOOP_BARRIER(c);
         GT_HIP(hipMemsetAsync(d->tmp, 0, p->y_elems * 4, s));
         for (int r = 0; r < c.n; r++) k_add_u32<<<1024, 256, 0, s>>>(d->tmp, c.peer[r].y, p->y_elems);
         GT_HIP(hipStreamSynchronize(s));
-        c.barrier();                                          // everybody has read everybody's partial counts
+        GT_LOOP_BARRIER(c);                                          // everybody has read everybody's partial counts
         GT_HIP(hipMemcpyAsync(p->y, d->tmp, p->y_elems * 4, hipMemcpyDeviceToDevice, s));
         return GT_OK;
     }
@@ -881,8 +887,15 @@ int gt_dist_all_reduce_u64(gt_dist *d, uint64_t *host_values, uint32_t count) {
 }
 
 // Vertex_Program::execute (vp:408-441) over the ranks of `d`: every rank calls it with its own program of the same kind.
+static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats);
 int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     GT_REQUIRE(d && p, GT_ERR_INVALID, "null argument");
+    if (d->loop && d->loop->aborted) { gt_set_error("rank %d: a peer of this loopback group failed in an earlier execute", d->rank); return GT_ERR_STATE; }
+    const int st = dist_execute_impl(d, p, iters, stats);
+    if (st != GT_OK && d->loop) d->loop->abort();   // the peers of a failed rank leave their barriers (with results that mean nothing) instead of hanging
+    return st;
+}
+static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     const gt_graph *g = p->g;
     GT_REQUIRE(gt_has_exchange(g), GT_ERR_STATE, "gt_dist_execute needs a graph built with the exchange layout (nranks > 1, or GRAPHTAP_FORCE_EXCHANGE)");
     GT_REQUIRE((int)g->info.nranks == d->nranks && (int)g->info.rank == d->rank, GT_ERR_INVALID,
@@ -893,7 +906,7 @@ int gt_dist_execute(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_stats *st
     const uint32_t K = g->info.x_slices;
     hipStream_t s = p->stream;
     d->sp_graph = nullptr;   // block tables of the sparse exchange: rebuilt per call (a freed graph's address may come back)
-    if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; c.barrier(); }
+    if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; GT_LOOP_BARRIER(c); }
     (void)gt_program_enable_timing(p, stats != nullptr);
     d->timing = stats != nullptr; d->t_iter = 0; d->t_mode.clear();
     d->list_iters = d->pair_spmspv_iters = d->round_trips = 0;

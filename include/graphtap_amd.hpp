@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -81,15 +82,29 @@ struct Env {
                 kids.push_back(c);
             }
             if (me < 0) {   // the launcher itself: never initialises the GPU
+                // the first rank that ends badly ends the run: its peers would wait for it in a collective for ever
                 int worst = 0;
-                for (pid_t c : kids) { int st = 0; waitpid(c, &st, 0); const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st); if (code > worst) worst = code; }
+                for (size_t left = kids.size(); left > 0; left--) {
+                    int st = 0;
+                    const pid_t c = waitpid(-1, &st, 0);
+                    if (c < 0) break;
+                    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+                    if (code > worst) worst = code;
+                    if (code != 0) {
+                        fprintf(stderr, "graphtap launcher: a rank process ended with status %d: stopping the others\n", code);
+                        for (pid_t k : kids) if (k != c) kill(k, SIGTERM);
+                    }
+                }
                 _exit(worst);
             }
             rank() = me; nranks() = n; local = me;
             if (getenv("GRAPHTAP_SHARE_GPU")) local = 0;
             check(gt_set_device(local));
             if (me == 0) { check(gt_dist_unique_id((void *)pg->id)); __sync_synchronize(); pg->ready = 1; }
-            else while (!pg->ready) usleep(1000);
+            else for (int tries = 0; !pg->ready; tries++) {   // (rank 0 gone before it published the id: the launcher ends us; the bound is for an outside kill of the launcher)
+                if (tries > 120000) throw Error("Env::init: timed out waiting for rank 0's RCCL unique id");
+                usleep(1000);
+            }
             __sync_synchronize();
             memcpy(id, (const void *)pg->id, sizeof(id));
         } else if (ws && rk && atoi(ws) >= 1) {
