@@ -716,7 +716,7 @@ int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::
             st = dense_prepare_send(d, p, s, my_flag != 0); if (st != GT_OK) return st;
             st = all_reduce_vec(d, s, nullptr, nullptr, nullptr, nullptr); if (st != GT_OK) return st;
         } else d->list_iters++;
-        if (my_flag == 0) p->x_stale = true;   // no messenger ran for this iteration: the next dense one rewrites every message
+        if (my_flag == 0) { p->x_stale = true; p->x_fresh = false; }   // no messenger ran for this iteration: the next dense one rewrites every message
         take_counts(d, NB);
         uint64_t total = 0; bool all_pairs = true;
         for (uint32_t b = 0; b < NB; b++) { if (d->form_recv[b]) total += d->cnt_recv[b]; else if (d->rtab[b].len) all_pairs = false; }
@@ -911,7 +911,7 @@ static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_
     d->timing = stats != nullptr; d->t_iter = 0; d->t_mode.clear();
     d->list_iters = d->pair_spmspv_iters = d->round_trips = 0;
     if (!d->loop && rccl()->CommCount && d->comm) (void)rccl()->CommCount(d->comm, &d->rccl_ranks);
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
     k_dist_preload<<<1, 64, 0, s>>>();   // this file's code object is loaded at its first launch (milliseconds): not inside the timed loop
     GT_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();

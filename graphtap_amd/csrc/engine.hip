@@ -196,18 +196,34 @@ __device__ __forceinline__ bool apply_row(uint32_t v, uint32_t yv, uint32_t *__r
         return nv != tmp;
     }
 }
-// every row
-template <bool BFS>
+// every row. MSG: the applicator also writes the NEXT iteration's message of the row's vertex -- its new value if it changed,
+// infinity() otherwise (vp:749-750) -- through the row -> slot map, as PageRank's fused applicator does: the full messenger pass
+// of the next scatter_gather (a gather of C and the state through slot -> vertex: 0.14-0.4 ms in the iterations that run a full
+// apply) disappears.
+template <bool BFS, bool MSG>
 __global__ void __launch_bounds__(TPB) k_apply_rows(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
                                                     uint32_t *__restrict__ s0, uint32_t *__restrict__ s1, uint8_t *__restrict__ C, uint32_t iteration,
-                                                    unsigned long long *d_active) {
+                                                    unsigned long long *d_active, uint32_t *__restrict__ x, const uint32_t *__restrict__ R2X,
+                                                    uint32_t vid_base, gt_vidmap vm) {
     unsigned act = 0;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
         const uint32_t v = IR[r];
         const bool c = apply_row<BFS>(v, y[r], s0, s1, iteration);
         C[v] = c; act += c;
+        if constexpr (MSG) {
+            const uint32_t sl = R2X[r];
+            if (sl != 0xFFFFFFFFu) x[sl] = c ? (BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+        }
     }
     count_active(act, d_active);
+}
+// once per initialize(), with the first fused apply: the columns of vertices WITHOUT a row (no in-edges: no apply ever visits
+// them) sent what they had to send in iteration 0 (the root; every vertex for CC) and are inactive from then on
+__global__ void k_reset_rowless_messages(uint32_t *__restrict__ x, const uint32_t *__restrict__ XV, uint32_t nslots, const uint8_t *__restrict__ IJ) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nslots; j += gridDim.x * blockDim.x) {
+        const uint32_t v = XV[j];
+        if (v != 0xFFFFFFFFu && !(IJ[v] & 1u)) x[j] = GT_INF;
+    }
 }
 // the list of the vertices a full apply changed, from their flags -- run only when the count it returned fits a list (appending
 // inside the full apply costs two barriers and a reservation per 256 rows: 1.5 instead of 0.3 ms when millions change). A
@@ -596,7 +612,7 @@ static int init_common(gt_program *p) {
     const uint32_t H = g->info.tile_height, base = g->info.rank * H;
     hipStream_t s = p->stream;
     static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
-    p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter;
+    p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter; p->rowless_reset = false; p->x_fresh = false;
     if (p->f32_capable && !p->x_f32) { p->x_f32 = true; p->x_bytes = 4; }   // back to the f32 messages a converge-mode run had left (gt_program_prepare)
     p->last_active = (p->prm.kind == GT_BFS || p->prm.kind == GT_SSSP) ? 1 : ~0ull;   // the root alone is active (bfs.h:37-50, sssp.h:33-42)
     switch (p->prm.kind) {
@@ -831,7 +847,15 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         p->y_clean = false;
     }
     auto timing_event = [&](hipEvent_t *out) -> int {
-        if (p->ev_used + 1 > p->ev.size()) { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
+        if (p->ev_used + 1 > p->ev.size()) {
+            // the pairs recorded so far are folded into a running sum and their events used again (a drain of the stream every
+            // 32 SpMVs; no event is created inside the iteration loop). Only at a pair boundary: a sliced SpMV holds one open.
+            if ((p->ev_used & 1) == 0) {
+                GT_HIP(hipStreamSynchronize(s));
+                for (size_t i = 0; i + 1 < p->ev_used; i += 2) { float ms = 0; GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1])); p->ev_acc_ms += ms; p->ev_acc_pairs++; }
+                p->ev_used = 0;
+            } else { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
+        }
         *out = p->ev[p->ev_used++];
         return GT_OK;
     };
@@ -943,13 +967,14 @@ int gt_program_timing(gt_program *p, double *spmv_ms, uint32_t *launches, int re
     GT_REQUIRE(p && spmv_ms && launches, GT_ERR_INVALID, "null argument");
     GT_HIP(hipStreamSynchronize(p->stream));
     *spmv_ms = 0; *launches = 0;
+    *spmv_ms = p->ev_acc_ms;
     for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
         float ms = 0;
         GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
         *spmv_ms += ms;
     }
     *launches = p->spmv_done;   // complete SpMVs (a sliced SpMV contributes one event pair per slice to the sum)
-    if (reset) { p->ev_used = 0; p->spmv_done = 0; }
+    if (reset) { p->ev_used = 0; p->spmv_done = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0; }
     return GT_OK;
 }
 
@@ -1011,8 +1036,23 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
                 else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap);
                 p->list_iters++;
             } else {
-                if (nr && bfs) k_apply_rows<true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
-                else if (nr) k_apply_rows<false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active);
+                // the full apply writes the next iteration's messages itself: every vertex with a row gets its slot rewritten (so x is
+                // exact afterwards even if it was stale); the vertices without a row had their say in iteration 0 and are reset once
+                static const bool fuse_msg = !(getenv("GRAPHTAP_FUSE_MIN_MSG") && atoi(getenv("GRAPHTAP_FUSE_MIN_MSG")) == 0);
+                // (not for BFS where bottom-up steps are possible: the iterations after its full applies read no messages, A/B:
+                // apply 0.34 -> 0.45 ms on R-MAT-25 for a messenger that was going to be skipped anyway)
+                const bool msg = fuse_msg && nr && !(bfs && p->bu_rows);
+                uint32_t *xm = (uint32_t *)(p->xseg ? p->xseg : p->x);
+                const uint32_t vb = g->info.rank * g->info.tile_height;
+                if (msg && !p->rowless_reset) {
+                    k_reset_rowless_messages<<<grid_for(gt_x_owned(g)), TPB, 0, s>>>(xm, gt_x_vertex(g), gt_x_owned(g), g->IJ);
+                    p->rowless_reset = true;
+                }
+                if (nr && bfs && msg) k_apply_rows<true, true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, xm, gt_row_slot(g), vb, gt_vidmap_of(g));
+                else if (nr && bfs) k_apply_rows<true, false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, nullptr, nullptr, 0, gt_vidmap_of(g));
+                else if (nr && msg) k_apply_rows<false, true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, xm, gt_row_slot(g), vb, gt_vidmap_of(g));
+                else if (nr) k_apply_rows<false, false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, nullptr, nullptr, 0, gt_vidmap_of(g));
+                if (msg) { p->x_fresh = true; p->x_stale = false; }
                 list_from_flags = lists;   // once the count is known (apply_finish) -- or at once when nobody is going to read it first
                 if (lists && deferred && nr)   // (the kernel stops appending at the list's capacity; the count tells whether the list is whole)
                     k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, next, next_n, p->fl_cap);
@@ -1089,7 +1129,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     { int st = gt_program_prepare(p, iters); if (st != GT_OK) return st; }   // vp:410-413 + the message width of this run
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->spmspv_allocs = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->spmspv_allocs = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
     GT_HIP(hipStreamSynchronize(s));
     const uint32_t val_allocs0 = gt_pb_val_allocs(p->g);
     const size_t ev0 = p->ev.size();
@@ -1133,6 +1173,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
         stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = p->list_iters;
         stats->allocs_in_execute = (gt_pb_val_allocs(p->g) - val_allocs0) + p->spmspv_allocs + (uint32_t)(p->ev.size() - ev0);
+        stats->spmv_ms = p->ev_acc_ms; stats->spmv_launches = p->ev_acc_pairs;
         for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
             float ms = 0;
             GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));

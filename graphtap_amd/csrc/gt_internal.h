@@ -157,6 +157,7 @@ struct gt_program {
     bool y_clean = false;       // y was zeroed by the fused apply
     std::vector<hipEvent_t> ev;  // SpMV timing pairs
     size_t ev_used = 0;
+    double ev_acc_ms = 0; uint32_t ev_acc_pairs = 0;   // pairs folded away when the 64 events were used up (engine.hip, timing_event)
     bool timing = false;
     uint32_t spmv_done = 0;     // complete SpMVs among the timed event pairs (a sliced SpMV records one pair per slice)
     uint64_t init_epoch = 0;    // bumped by every initialize(): scopes the activity filtering of the min programs
@@ -197,6 +198,7 @@ struct gt_program {
     // a bottom-up step reads no messages: scatter_gather() defers the messenger when such a step is likely, combine runs it
     // after all if the step is declined, and x is marked stale (the next messenger rewrites all of it) if it was not needed
     bool x_deferred = false, x_stale = false;
+    bool rowless_reset = false;   // the messages of vertices without a row were reset once (first apply that wrote messages itself)
     bool pack_deferred = false;   // scatter_gather leaves the per-destination packing to gt_program_pack_slice (the C++ multi-rank driver)
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
