@@ -70,6 +70,7 @@ SIGNATURES = {
     "gt_device_count": (C.c_int, []),
     "gt_set_device": (C.c_int, [C.c_int]),
     "gt_graph_build": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int]),
+    "gt_graph_build_distributed": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags)]),
     "gt_graph_info_get": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
     "gt_graph_select_spmv": (C.c_int, [_vp, C.c_int]),
     "gt_graph_vertex_ids": (C.c_int, [_vp, _vp, C.c_uint64]),

@@ -226,9 +226,13 @@ __global__ void __launch_bounds__(256) k_pairs_frontier(const uint2 *__restrict_
     }
 }
 
+// ---- collectives of the distributed build (Matrix::distribute, mat/matrix.hpp:693-810): both transports
+__global__ void k_max_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) if (src[i] > dst[i]) dst[i] = src[i];
+}
 // ---- loopback: what the p ranks of one process share
 struct LoopPeer { const char *send = nullptr; const uint32_t *y = nullptr; const gt_graph *g = nullptr; uint32_t x_bytes = 0; uint64_t word = 0;
-                  const uint2 *pairs = nullptr; const unsigned long long *words = nullptr; const uint32_t *counts = nullptr; /* host [K*P] active messages per send block, or null = all dense */ };
+                  const uint2 *pairs = nullptr; const unsigned long long *words = nullptr; const uint32_t *counts = nullptr; const void *coll = nullptr; /* host [K*P] active messages per send block, or null = all dense */ };
 struct LoopCtx {
     int n = 0;
     std::mutex mu;
@@ -779,6 +783,61 @@ int all_reduce_y(gt_dist *d, gt_program *p, hipStream_t s) {
 }
 
 }  // namespace
+
+// every rank sends bytes [send_off[q], send_off[q] + send_bytes[q]) of `send` to rank q and receives recv_bytes[q] bytes from it at
+// recv_off[q] of `recv` (an all-to-all-v; the byte counts were agreed before: send_bytes[q] here = recv_bytes[me] on rank q)
+int gt_dist_exchange_bytes(gt_dist *d, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv, const uint64_t *recv_off,
+                           const uint64_t *recv_bytes, hipStream_t s) {
+    const int P = d->nranks;
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        struct Pub { const void *send; const uint64_t *off, *bytes; } mine{send, send_off, send_bytes};
+        GT_HIP(hipStreamSynchronize(s));
+        c.peer[d->rank].coll = &mine;
+        GT_LOOP_BARRIER(c);
+        for (int q = 0; q < P; q++) {
+            const Pub *pq = (const Pub *)c.peer[q].coll;
+            GT_REQUIRE(pq->bytes[d->rank] == recv_bytes[q], GT_ERR_STATE, "exchange of the build: rank %d sends %llu bytes to rank %d, which expects %llu", q,
+                       (unsigned long long)pq->bytes[d->rank], d->rank, (unsigned long long)recv_bytes[q]);
+            if (recv_bytes[q]) GT_HIP(hipMemcpyAsync((char *)recv + recv_off[q], (const char *)pq->send + pq->off[d->rank], recv_bytes[q], hipMemcpyDeviceToDevice, s));
+        }
+        GT_HIP(hipStreamSynchronize(s));
+        GT_LOOP_BARRIER(c);
+        return GT_OK;
+    }
+    GT_NCCL(rccl()->GroupStart());
+    for (int q = 0; q < P; q++) {
+        if (send_bytes[q]) GT_NCCL(rccl()->Send((const char *)send + send_off[q], send_bytes[q], ncclUint8, q, d->comm, s));
+        if (recv_bytes[q]) GT_NCCL(rccl()->Recv((char *)recv + recv_off[q], recv_bytes[q], ncclUint8, q, d->comm, s));
+    }
+    GT_NCCL(rccl()->GroupEnd());
+    return sync_deadline(d, s, "the record exchange of the distributed build");
+}
+// element-wise maximum over the ranks, in place (flags: a logical OR)
+int gt_dist_all_reduce_max_u8(gt_dist *d, uint8_t *buf, uint64_t n, hipStream_t s) {
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        uint8_t *tmp = nullptr;
+        GT_HIP(hipMalloc((void **)&tmp, n ? n : 1));
+        GT_HIP(hipMemcpyAsync(tmp, buf, n, hipMemcpyDeviceToDevice, s));
+        GT_HIP(hipStreamSynchronize(s));
+        c.peer[d->rank].coll = tmp;   // the peers read the copy: everybody may overwrite its own buffer at once
+        GT_LOOP_BARRIER(c);
+        for (int q = 0; q < c.n; q++) if (q != d->rank) k_max_u8<<<1024, 256, 0, s>>>(buf, (const uint8_t *)c.peer[q].coll, n);
+        GT_HIP(hipStreamSynchronize(s));
+        GT_LOOP_BARRIER(c);
+        (void)hipFree(tmp);
+        return GT_OK;
+    }
+    GT_NCCL(rccl()->AllReduce(buf, buf, n, ncclUint8, ncclMax, d->comm, s));
+    return sync_deadline(d, s, "the all-reduce of the column flags (distributed build)");
+}
+int gt_dist_all_reduce_sum_u64_host(gt_dist *d, uint64_t *v, uint32_t count) {
+    for (uint32_t i = 0; i < count; i += 64) { int st = dist_all_reduce_words(d, v + i, std::min(64u, count - i), d->loop ? (hipStream_t)0 : d->comm_stream); if (st != GT_OK) return st; }
+    return GT_OK;
+}
+int gt_dist_rank(const gt_dist *d) { return d->rank; }
+int gt_dist_nranks(const gt_dist *d) { return d->nranks; }
 
 extern "C" {
 

@@ -369,8 +369,22 @@ int gt_graph_free(gt_graph *g) {
     return GT_OK;
 }
 
+static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist);
 int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
                    uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks) {
+    return graph_build_impl(out, edges, m, edges_on_device, weighted, num_vertices, flags, rank, nranks, nullptr);
+}
+// Matrix::distribute (mat/matrix.hpp:693-810): every rank brings a SHARE of the records (any split of the list); the build moves
+// each record to the owner of its row(s) and gets the global pieces from collectives over `dist`. Collective: every rank of the
+// communicator calls it. The result is the graph gt_graph_build gives for the same rank from the full list.
+int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_share, uint64_t m_share, int edges_on_device, int weighted,
+                               uint32_t num_vertices, const gt_graph_flags *flags) {
+    GT_REQUIRE(dist, GT_ERR_INVALID, "gt_graph_build_distributed: null communicator");
+    return graph_build_impl(out, edges_share, m_share, edges_on_device, weighted, num_vertices, flags, gt_dist_rank(dist), gt_dist_nranks(dist), dist);
+}
+static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist) {
     GT_REQUIRE(out && flags && (edges || m == 0), GT_ERR_INVALID, "gt_graph_build: null argument");
     GT_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, GT_ERR_INVALID, "gt_graph_build: rank %d of %d", rank, nranks);
     GT_REQUIRE(num_vertices < 0xFFFFFFF0u - (uint32_t)nranks, GT_ERR_INVALID, "num_vertices too large for 32-bit vertex ids");
@@ -418,7 +432,8 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
         t = now;
     };
     auto tb = std::chrono::steady_clock::now();
-    int st = gt_ingest(g, dev_edges, m, weighted);
+    if (dist && nranks == 1 && !g->force_exchange) dist = nullptr;   // one rank without the exchange layout: nothing to distribute
+    int st = gt_ingest(g, dev_edges, m, weighted, dist);
     tick("ingest (TCSC tile-row)", tb);
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }

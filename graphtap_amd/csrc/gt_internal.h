@@ -247,7 +247,18 @@ int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s)
 uint32_t gt_pb_val_allocs(const gt_graph *g);   // how many times VAL was (re)allocated so far
 uint64_t gt_pb_source_entries(const gt_graph *g);   // entries in chunks of source rows (left out by PageRank/TCSC_CF until the last iteration)
 
-int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted);
+// `d` != null: the DISTRIBUTED build -- `edges_dev` holds this rank's share of the records (any share); the records travel to the
+// owners of their rows and the global pieces of the build (column flags, what every peer needs of my columns, the entry count)
+// come from collectives over `d` (Matrix::distribute, mat/matrix.hpp:693-810)
+struct gt_dist;
+int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_dist *d = nullptr);
+// collectives of the distributed build (dist.hip; RCCL or the loopback transport)
+int gt_dist_exchange_bytes(gt_dist *d, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv, const uint64_t *recv_off,
+                           const uint64_t *recv_bytes, hipStream_t s);
+int gt_dist_all_reduce_max_u8(gt_dist *d, uint8_t *buf, uint64_t n, hipStream_t s);
+int gt_dist_all_reduce_sum_u64_host(gt_dist *d, uint64_t *v, uint32_t count);
+int gt_dist_rank(const gt_dist *d);
+int gt_dist_nranks(const gt_dist *d);
 
 // tcsc_cf.hip
 int gt_tcsc_cf_build(gt_graph *g);

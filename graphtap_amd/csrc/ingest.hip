@@ -42,12 +42,13 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
                          uint8_t *__restrict__ rowflag, uint8_t *__restrict__ colflag,
                          uint32_t *__restrict__ needme /* [span] entries this tile-row has in every column, or null on one rank */,
                          uint32_t *__restrict__ needby /* [nranks][H] entries tile-row d has in every owned column, or null */,
-                         unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */) {
+                         unsigned long long *__restrict__ counters /* [0]=kept [1]=out-of-range [2]=global entries */,
+                         bool shuffled /* the records are this rank's after the shuffle: [2] counts the kept entries only (the ranks add up) */) {
     unsigned long long bad = 0, glob = 0;
     const uint32_t lane = threadIdx.x & 63;
     // non-empty ROWS are only needed for the owned segment (compressed row ids are segment-local); the non-empty COLUMNS of
     // every segment are needed everywhere (the exchange layout numbers a source segment's columns by compressed id)
-    const bool all_rows = (needby == nullptr);
+    const bool all_rows = (needme == nullptr);   // one rank without the exchange layout
     auto below = [](uint64_t mk) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0)); };
     // COMPACTING: only the entries of this rank's tile-row are written (a rank of p sorts ~m/p keys, not m). A WORKGROUP
     // reserves room for what it keeps with one atomic per round (one per wave was 16.7 M atomics on one address for R-MAT-26:
@@ -74,14 +75,14 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
                 // replaces a scattered one-byte write (a read-modify-write of a sector at the memory side)
                 auto set = [](uint8_t *__restrict__ flags, uint64_t i) { if (!flags[i]) flags[i] = 1; };
                 if (all_rows || (row >= row_lo && row < row_hi)) set(rowflag, row);
-                set(colflag, col); glob++;
+                set(colflag, col); glob += (!shuffled || (row >= row_lo && row < row_hi));
                 // counts, not flags: both sides of an exchange block order its columns by these (descending), so the receiver's
                 // count of column c and the owner's count for that receiver must come from the same records -- they do
                 if (row >= row_lo && row < row_hi) { k0 = ((uint64_t)col << 32) | row; keep0 = true; if (needme) atomicAdd(&needme[col], 1u); }
                 if (needby && col >= row_lo && col < row_hi) atomicAdd(&needby[(uint64_t)(row / H) * H + (col - row_lo)], 1u);
                 if (!f.directed) {
                     if (all_rows || (col >= row_lo && col < row_hi)) set(rowflag, col);
-                    set(colflag, row); glob++;
+                    set(colflag, row); glob += (!shuffled || (col >= row_lo && col < row_hi));
                     if (col >= row_lo && col < row_hi) { k1 = ((uint64_t)row << 32) | col; keep1 = true; if (needme) atomicAdd(&needme[row], 1u); }
                     if (needby && row >= row_lo && row < row_hi) atomicAdd(&needby[(uint64_t)(col / H) * H + (row - row_lo)], 1u);
                 }
@@ -111,6 +112,68 @@ __global__ void __launch_bounds__(EXPAND_TPB) k_expand(const uint32_t *__restric
         if (glob) atomicAdd(&counters[2], glob);
     }
 }
+
+// ---- distributed build: where a record has to go (Matrix::distribute, mat/matrix.hpp:693-810). A record becomes one stored entry
+// (row, col) -- two for an undirected graph -- after the flag handling of k_expand; it travels to the owner(s) of the entries' rows
+// (owner = internal row id / H). Records k_expand would drop or reject stay with this rank (it reports the bad ones).
+__device__ __forceinline__ void record_owners(const uint32_t *__restrict__ rec, uint64_t e, int stride, gt_graph_flags f, uint32_t nrows, uint32_t perm_a,
+                                              uint32_t perm_mask, uint32_t H, uint32_t me, uint32_t &d0, uint32_t &d1) {
+    uint32_t row = rec[e * stride], col = rec[e * stride + 1];
+    d0 = me; d1 = 0xFFFFFFFFu;
+    if (row >= nrows || col >= nrows) return;            // out of range: counted as bad by my own k_expand
+    if (row == col && !f.self_loops) return;             // dropped anyway
+    if (f.acyclic && col < row) { uint32_t t = row; row = col; col = t; }
+    if (f.transpose) { uint32_t t = row; row = col; col = t; }
+    row = (row * perm_a) & perm_mask; col = (col * perm_a) & perm_mask;
+    d0 = row / H;
+    if (!f.directed) { const uint32_t o = col / H; if (o != d0) d1 = o; }
+}
+__global__ void __launch_bounds__(256) k_route_count(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f, uint32_t nrows, uint32_t perm_a,
+                                                     uint32_t perm_mask, uint32_t H, uint32_t me, uint32_t p, unsigned long long *__restrict__ counts) {
+    extern __shared__ unsigned int hist[];
+    for (uint32_t i = threadIdx.x; i < p; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t d0, d1;
+        record_owners(rec, e, stride, f, nrows, perm_a, perm_mask, H, me, d0, d1);
+        atomicAdd(&hist[d0], 1u);
+        if (d1 != 0xFFFFFFFFu) atomicAdd(&hist[d1], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < p; i += blockDim.x) if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+// records into the send buffer, grouped by destination: a workgroup reserves room per destination once per round
+__global__ void __launch_bounds__(256) k_route_fill(const uint32_t *__restrict__ rec, uint64_t m, int stride, gt_graph_flags f, uint32_t nrows, uint32_t perm_a,
+                                                    uint32_t perm_mask, uint32_t H, uint32_t me, uint32_t p, const unsigned long long *__restrict__ base,
+                                                    unsigned long long *__restrict__ cursor, uint32_t *__restrict__ out) {
+    extern __shared__ unsigned int sh[];   // [p] this round's counts, then the workgroup's slots; [p] 64-bit bases behind them
+    unsigned int *cnt = sh;
+    unsigned long long *wbase = reinterpret_cast<unsigned long long *>(sh + ((p + 1) & ~1u));
+    const uint64_t m_round = (m + blockDim.x - 1) / blockDim.x * blockDim.x;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < m_round; e += (uint64_t)gridDim.x * blockDim.x) {
+        for (uint32_t i = threadIdx.x; i < p; i += blockDim.x) cnt[i] = 0;
+        __syncthreads();
+        uint32_t d0 = 0xFFFFFFFFu, d1 = 0xFFFFFFFFu, s0 = 0, s1 = 0;
+        if (e < m) {
+            record_owners(rec, e, stride, f, nrows, perm_a, perm_mask, H, me, d0, d1);
+            s0 = atomicAdd(&cnt[d0], 1u);
+            if (d1 != 0xFFFFFFFFu) s1 = atomicAdd(&cnt[d1], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < p; i += blockDim.x) wbase[i] = cnt[i] ? atomicAdd(&cursor[i], (unsigned long long)cnt[i]) : 0ull;
+        __syncthreads();
+        if (e < m) {
+            for (int w = 0; w < 2; w++) {
+                const uint32_t dd = w ? d1 : d0;
+                if (dd == 0xFFFFFFFFu) continue;
+                const unsigned long long o = base[dd] + wbase[dd] + (w ? s1 : s0);
+                for (int j = 0; j < stride; j++) out[o * stride + j] = rec[e * stride + j];
+            }
+        }
+        __syncthreads();
+    }
+}
+// needby of destination q = what q's tile-row has in MY columns = q's needme over my segment
 
 struct U8ToU32 {
     __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; }
@@ -292,7 +355,7 @@ __global__ void k_segment_vectors(const uint8_t *__restrict__ rowflag, const uin
         if ((buf).alloc(bytes)) { gt_set_error("ingest: out of device memory (%llu bytes)", (unsigned long long)(bytes)); return GT_ERR_HIP; } \
     } while (0)
 
-int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
+int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_dist *dist) {
     const gt_graph_flags f = g->flags;
     const uint32_t p = g->info.nranks, k = g->info.rank, H = g->info.tile_height, nrows = g->info.nrows;
     const uint64_t span = (uint64_t)p * H;             // vertex slots of the whole grid (>= nrows)
@@ -300,18 +363,47 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
     const uint32_t row_hi = (uint32_t)(((uint64_t)(k + 1) * H < g->nint) ? (uint64_t)(k + 1) * H : g->nint);
     const int stride = weighted ? 3 : 2;
     const int slots = f.directed ? 1 : 2;
-    const uint64_t cap = m * slots;
     hipStream_t s = 0;
     // the exchange layout (local column space, send list, K slices): always on several ranks; on ONE rank only when
     // asked for (GRAPHTAP_FORCE_EXCHANGE), so that the whole multi-rank driver path -- RCCL self-exchange included --
     // runs on a one-GPU box
     const bool multi = p > 1 || g->force_exchange;
+    // ---- distributed build: this rank holds a SHARE of the records; they go to the owners of their rows first
+    DevBuf shuffled_buf;
+    if (dist) {
+        GT_REQUIRE(multi, GT_ERR_STATE, "the distributed build needs the exchange layout");
+        GT_REQUIRE(gt_dist_nranks(dist) == (int)p && gt_dist_rank(dist) == (int)k, GT_ERR_INVALID, "the communicator and the graph disagree on rank / nranks");
+        DevBuf cnt_d, base_d, cur_d, sendbuf;
+        ING_ALLOC(cnt_d, p * 8); ING_ALLOC(base_d, p * 8); ING_ALLOC(cur_d, p * 8);
+        ING_HIP(hipMemsetAsync(cnt_d.p, 0, p * 8, s)); ING_HIP(hipMemsetAsync(cur_d.p, 0, p * 8, s));
+        const unsigned rgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, 256u * 16u));
+        if (m) k_route_count<<<rgrid, 256, p * 4, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p, cnt_d.as<unsigned long long>());
+        std::vector<uint64_t> scount(p), soff(p), rcount(p), roff(p), matrix((size_t)p * p, 0);
+        ING_HIP(hipMemcpyAsync(scount.data(), cnt_d.p, p * 8, hipMemcpyDeviceToHost, s));
+        ING_HIP(hipStreamSynchronize(s));
+        uint64_t stotal = 0;
+        for (uint32_t q = 0; q < p; q++) { soff[q] = stotal; stotal += scount[q]; matrix[(size_t)k * p + q] = scount[q]; }
+        { int st = gt_dist_all_reduce_sum_u64_host(dist, matrix.data(), p * p); if (st != GT_OK) return st; }   // everybody learns every count
+        uint64_t rtotal = 0;
+        for (uint32_t q = 0; q < p; q++) { rcount[q] = matrix[(size_t)q * p + k]; roff[q] = rtotal; rtotal += rcount[q]; }
+        const uint64_t rb = (uint64_t)stride * 4;
+        ING_ALLOC(sendbuf, std::max<uint64_t>(stotal, 1) * rb); ING_ALLOC(shuffled_buf, std::max<uint64_t>(rtotal, 1) * rb);
+        ING_HIP(hipMemcpyAsync(base_d.p, soff.data(), p * 8, hipMemcpyHostToDevice, s));
+        if (m) k_route_fill<<<rgrid, 256, ((p + 1) & ~1u) * 4 + p * 8, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p,
+                                                                            base_d.as<unsigned long long>(), cur_d.as<unsigned long long>(), sendbuf.as<uint32_t>());
+        ING_HIP(hipGetLastError());
+        std::vector<uint64_t> sob(p), scb(p), rob(p), rcb(p);
+        for (uint32_t q = 0; q < p; q++) { sob[q] = soff[q] * rb; scb[q] = scount[q] * rb; rob[q] = roff[q] * rb; rcb[q] = rcount[q] * rb; }
+        { int st = gt_dist_exchange_bytes(dist, sendbuf.p, sob.data(), scb.data(), shuffled_buf.p, rob.data(), rcb.data(), s); if (st != GT_OK) return st; }
+        edges_dev = shuffled_buf.p; m = rtotal;
+    }
+    const uint64_t cap = m * slots;
 
     DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby, Pneed, Pby;
     // Room for the kept entries: everything on one rank; on several, the hashed id space spreads the entries evenly, so
     // 1.25 x the mean share (+ slack for small graphs) is reserved and the pass is repeated with the exact count in the
     // rare case it does not fit (a multi-GB hipMalloc is not free: 8.6 GB for every rank of 8 at R-MAT-26 otherwise).
-    uint64_t room = (p == 1) ? cap : std::min<uint64_t>(cap, cap / p + cap / (4 * p) + 65536);
+    uint64_t room = (p == 1 || dist) ? cap : std::min<uint64_t>(cap, cap / p + cap / (4 * p) + 65536);   // (after the shuffle every record is mine)
     ING_ALLOC(keys, room * 8);
     if (weighted) ING_ALLOC(wts, room * 4);
     ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
@@ -333,8 +425,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         k_expand<<<(unsigned)std::min<uint64_t>((m + EXPAND_TPB - 1) / EXPAND_TPB, 256u * 8u), EXPAND_TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
                                              keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
                                              rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
-                                             multi ? needme.as<uint32_t>() : nullptr, multi ? needby.as<uint32_t>() : nullptr,
-                                             counters.as<unsigned long long>());
+                                             multi ? needme.as<uint32_t>() : nullptr, (multi && !dist) ? needby.as<uint32_t>() : nullptr,
+                                             counters.as<unsigned long long>(), dist != nullptr);
         ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
         ING_HIP(hipStreamSynchronize(s));
         if (hc[0] <= room) break;
@@ -349,6 +441,14 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted) {
         gt_set_error("%llu edge record(s) name a vertex id > num_vertices=%u (the reference overflows its tile grid silently, "
                      "src/mat/matrix.hpp:218-220; this library rejects the input)", hc[1], g->info.num_vertices);
         return GT_ERR_INVALID;
+    }
+    if (dist) {
+        // the global pieces, from collectives: a column is non-empty if ANY tile-row has an entry in it; what tile-row q has in MY
+        // columns (the order of my send blocks) is q's own count over my segment
+        { int st = gt_dist_all_reduce_max_u8(dist, colflag.as<uint8_t>(), span + 1, s); if (st != GT_OK) return st; }
+        std::vector<uint64_t> off(p), bytes(p);
+        for (uint32_t q = 0; q < p; q++) { off[q] = (uint64_t)q * H * 4; bytes[q] = (uint64_t)H * 4; }
+        { int st = gt_dist_exchange_bytes(dist, needme.p, off.data(), bytes.data(), needby.p, off.data(), bytes.data(), s); if (st != GT_OK) return st; }
     }
     const uint64_t nvalid = hc[0];
     GT_REQUIRE(nvalid < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED,

@@ -213,6 +213,13 @@ int gt_set_device(int device);
  * nranks > 1 (see gt_graph_vertex_ids); every rank passes the SAME full edge list. The caller may free `edges` after the call returns. */
 int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
                    uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks);
+/* The same graph from a DISTRIBUTED edge list (Matrix::distribute, mat/matrix.hpp:693-810: the reference's ranks read the file in
+ * parallel and shuffle the triples to their owners): every rank of `dist` passes a share of the records -- any split of the
+ * list -- and the build sends each record to the owner(s) of its row(s); the global pieces (non-empty columns, what each peer
+ * needs of a rank's columns) come from collectives. Collective over the communicator; rank and nranks are the communicator's. */
+typedef struct gt_dist gt_dist;
+int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_share, uint64_t m_share, int edges_on_device, int weighted,
+                               uint32_t num_vertices, const gt_graph_flags *flags);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
 /* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
  * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
@@ -317,7 +324,6 @@ int gt_program_free(gt_program *p);
  * while phase 1 of slice k runs; the row-group reduce (vp:1083-1111) is gone (tile-rows make y complete locally; Degree
  * in GT_COL order is one ncclAllReduce); has_converged (vp:1918) and the checksums (vp:1940,1956) are ncclAllReduce of
  * 8-byte words. graphtap_amd/dist.py is the same loop over torch.distributed. */
-typedef struct gt_dist gt_dist;
 #define GT_DIST_UNIQUE_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 /* rank 0: a fresh RCCL unique id, to be handed to every rank by the launcher (file, pipe, MPI_Bcast ...) */
 int gt_dist_unique_id(void *id_out);

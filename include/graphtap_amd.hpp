@@ -16,6 +16,7 @@
 //  * weights are a run-time property of the Graph object (the reference uses -DHAS_WEIGHT);
 //  * V is struct-of-arrays copied out of HBM on demand (`V()`), not a std::vector of structs.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -161,25 +162,42 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
         std::ifstream fin(filepath, std::ios::binary | std::ios::ate);
         if (!fin.is_open()) throw Error("Unable to open input file");  // graph.hpp:311-314
         const uint64_t bytes = (uint64_t)fin.tellg(), rec = weighted_ ? 12 : 8;
-        std::vector<char> buf(bytes);
-        fin.seekg(0);
-        fin.read(buf.data(), (std::streamsize)bytes);
         // The reference tells text from binary with popen("file -b") (graph.hpp:119-145); here a file is text when its
         // first 4 KiB are printable ASCII / white space.
+        std::vector<char> buf((size_t)std::min<uint64_t>(bytes, 4096));
+        fin.seekg(0);
+        fin.read(buf.data(), (std::streamsize)buf.size());
         bool text = bytes > 0;
-        for (uint64_t i = 0; i < bytes && i < 4096 && text; i++) {
+        for (uint64_t i = 0; i < buf.size() && text; i++) {
             const unsigned char c = (unsigned char)buf[i];
             text = (c >= 32 && c < 127) || c == '\t' || c == '\n' || c == '\r';
         }
-        if (text) {
-            std::vector<uint32_t> recs = parse_text(buf, weighted_ ? 3 : 2);
-            const uint64_t m = recs.size() / (weighted_ ? 3 : 2);
+        if (!text && bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
+        if (!text && Env::dist() && !getenv("GRAPHTAP_REPLICATED_READ")) {
+            // several ranks, binary file: every rank reads ITS 1/p of the records (the reference's parallel read, graph.hpp:308-372)
+            // and the build shuffles them to the owners of their rows (Matrix::distribute, matrix.hpp:693-810)
+            const uint64_t m = bytes / rec, lo = m * (uint64_t)Env::rank() / (uint64_t)Env::nranks(), hi = m * ((uint64_t)Env::rank() + 1) / (uint64_t)Env::nranks();
+            std::vector<char> share((size_t)((hi - lo) * rec));
+            fin.seekg((std::streamoff)(lo * rec));
+            fin.read(share.data(), (std::streamsize)share.size());
             GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
-            load_edges(recs.data(), m, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+            free();
+            gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
+            check(gt_graph_build_distributed(&h_, Env::dist(), share.data(), hi - lo, 0, weighted_, nrows, &f));
+            after_build(compression_type);
         } else {
-            if (bytes % rec) throw Error("read() failure");                // graph.hpp:331-334
-            GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
-            load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+            buf.resize((size_t)bytes);
+            fin.seekg(0);
+            fin.read(buf.data(), (std::streamsize)bytes);
+            if (text) {
+                std::vector<uint32_t> recs = parse_text(buf, weighted_ ? 3 : 2);
+                const uint64_t m = recs.size() / (weighted_ ? 3 : 2);
+                GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
+                load_edges(recs.data(), m, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+            } else {
+                GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)(bytes / rec));
+                load_edges(buf.data(), bytes / rec, nrows, directed, transpose, self_loops, acyclic, parallel_edges, compression_type);
+            }
         }
         GT_MASTER_PRINTF("Ingress time: %f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
@@ -218,9 +236,11 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
                     bool acyclic, bool parallel_edges, Compression_type compression_type, bool on_device = false) {
         free();
         gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
-        // every rank reads the whole edge list and keeps its tile-row (the reference's ranks read 1/p each and shuffle,
-        // matrix.hpp:693-810; here the device ingest filters)
+        // (an in-memory list: every rank passes all of it and keeps its tile-row; files go through the distributed build above)
         check(gt_graph_build(&h_, edges, m, on_device, weighted_, num_vertices, &f, Env::rank(), Env::nranks()));
+        after_build(compression_type);
+    }
+    void after_build(Compression_type compression_type) {
         check(gt_graph_info_get(h_, &info));
         compression = compression_type;
         nnz_global = info.nnz_local;

@@ -233,6 +233,79 @@ def test_frontier_lists_on_several_ranks_are_bit_exact(gt, name, nranks, slices,
         assert tot["list"] == 0
 
 
+@pytest.mark.parametrize("split", ["contiguous", "round_robin", "all_on_rank_0"])
+@pytest.mark.parametrize("nranks,slices", [(2, 2), (3, 1), (8, 2)])
+@pytest.mark.parametrize("name,app", [("tiny", "pr"), ("rmat10", "bfs"), ("rmat12", "sssp"), ("rmat12", "pr")])
+def test_distributed_build_equals_the_replicated_build(gt, name, app, nranks, slices, split, monkeypatch, known_answers):
+    """Matrix::distribute (mat/matrix.hpp:693-810): every rank brings a share of the records, the build shuffles them to the owners
+    of their rows and takes the global pieces from collectives. Whatever the split, rank r's graph is the one gt_graph_build
+    gives it from the full list -- info, TCSC arrays, exchange plan -- and the programs run on it to the reference's vectors."""
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    weighted = app == "sssp"
+    e = c["wedges"] if weighted else c["edges"]
+    flags = {"pr": (True, True, True, False, True), "bfs": (False, False, False, False, False), "sssp": (True, True, False, False, False)}[app]
+    ct = gt._TCSC_CF_ if app == "pr" else gt._TCSC_
+    shares = {"contiguous": [e[len(e) * r // nranks: len(e) * (r + 1) // nranks] for r in range(nranks)],
+              "round_robin": [e[r::nranks] for r in range(nranks)],
+              "all_on_rank_0": [e if r == 0 else e[:0] for r in range(nranks)]}[split]
+    hs = (C.c_void_p * nranks)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, nranks))
+    dists = [C.c_void_p(hs[r]) for r in range(nranks)]
+    Gs, errs = [None] * nranks, [None] * nranks
+
+    def build(r):
+        try:
+            L.gt_set_device(0)
+            G = gt.Graph(weighted=weighted)
+            G.load_share(dists[r], r, nranks, shares[r], nv, nv, *flags, gt._2DT_, ct)
+            Gs[r] = G
+        except Exception as ex:   # noqa: BLE001
+            errs[r] = ex
+    ts = [threading.Thread(target=build, args=(r,)) for r in range(nranks)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not any(errs), errs
+    try:
+        for r in range(nranks):
+            R = gt.Graph(weighted=weighted); R.load_edges(e, nv, nv, *flags, gt._2DT_, ct, rank=r, nranks=nranks)
+            a, b = Gs[r].info, R.info
+            for f, _ in a._fields_:
+                assert getattr(a, f) == getattr(b, f), (r, f, getattr(a, f), getattr(b, f))
+            ta, tb = Gs[r].tile_to_host(), R.tile_to_host()
+            for k in ta:
+                if ta[k] is None: assert tb[k] is None
+                elif k == "A":   # duplicates of a (row, col) pair keep the minimum weight either way; equal after sorting inside a column is implied by IA equality + dedupe
+                    assert (ta[k] == tb[k]).all(), (r, k)
+                else: assert (ta[k] == tb[k]).all(), (r, k)
+            pa, pb = Gs[r].exchange_plan(), R.exchange_plan()
+            assert pa == pb, (r, "exchange plan")
+            R.free()
+        if app == "pr":
+            degs = [gt.Deg_Program(G, True, False, False, gt._COL_) for G in Gs]
+            for p in degs: p.initialize()
+            _dist_execute_all(gt, dists, degs, 1)
+            ps = [gt.PR_Program(G, True, False, False, gt._ROW_) for G in Gs]
+            for p, d in zip(ps, degs): p.initialize(d)
+            _dist_execute_all(gt, dists, ps, 20)
+            ref = c["np1_pr20_c"]
+            assert (np.abs(_gather(ps, "rank", n) - ref) / ref).max() < PR_RTOL
+            for p in ps + degs: p.free()
+        else:
+            ps = [(gt.BFS_Program(G, False, False, True, gt._ROW_) if app == "bfs" else gt.SSSP_Program(G, False, True, False, gt._ROW_)) for G in Gs]
+            for p in ps: p.root = c["root"]; p.initialize()
+            it, conv = _dist_execute_all(gt, dists, ps, 0)
+            assert conv and it == known_answers[name]["np1_" + app]["iterations"]
+            f, gold = ("parent", "np1_bfs_a") if app == "bfs" else ("distance", "np1_sssp_a")
+            assert (_gather(ps, f, n) == c[gold]).all()
+            for p in ps: p.free()
+    finally:
+        for G in Gs:
+            if G is not None: G.free()
+        for d in dists: L.gt_dist_free(d)
+
+
 def _app(app, args, env_extra):
     exe = os.path.join(ROOT, "apps", "bin", app)
     if not os.path.exists(exe):
