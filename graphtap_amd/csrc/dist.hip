@@ -294,6 +294,7 @@ struct gt_dist {
     std::vector<hipEvent_t> tev;                     // per iteration: start, messages packed, SpMV done, apply done, first slice in, last slice in
     size_t tev_used = 0;
     int rccl_ranks = 0;
+    uint64_t plan_checked = 0;                       // serial of the graph whose exchange plan was verified against the peers'
     bool timing = false; uint32_t t_iter = 0;        // events are recorded for the first GT_DIST_TIMED_ITERS iterations of a timed execute
     std::vector<uint8_t> t_mode;                     // per timed iteration: 0 dense blocks, 1 pairs scattered into x, 2 SpMSpV from the pairs
     std::vector<double> iter_ms;                     // [iterations][GT_DIST_TIME_FIELDS], filled when the execute ends
@@ -372,6 +373,34 @@ int sync_deadline(gt_dist *d, hipStream_t s, const char *what) {
             return GT_ERR_HIP;
         }
     }
+}
+
+// Once per (communicator, graph): every rank's send counts against every receiver's recv counts. A mismatch (graphs built from
+// different edge lists or flags, a different GRAPHTAP_X_SLICES on some rank) would make the grouped send/recv rounds hang or
+// scribble; it is reported instead.
+int plan_verify(gt_dist *d, const gt_graph *g) {
+    if (d->plan_checked == g->serial) return GT_OK;
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, me = g->info.rank;
+    {   // first the shape (a fixed-size collective): the ranks must agree on K and P before a K x P x P matrix can be summed
+        uint64_t w[3] = {K, (uint64_t)K * K, 1};
+        int st = gt_dist_all_reduce_sum_u64_host(d, w, 3); if (st != GT_OK) return st;
+        GT_REQUIRE(w[2] == P && w[0] == (uint64_t)K * P && w[1] == (uint64_t)K * K * P, GT_ERR_STATE,
+                   "exchange plan: the ranks disagree on the number of slices or of ranks (this rank: %u slices, %u ranks; %llu ranks answered, their slices sum to %llu): "
+                   "the same GRAPHTAP_X_SLICES and nranks everywhere?", K, P, (unsigned long long)w[2], (unsigned long long)w[0]);
+    }
+    std::vector<uint64_t> m((size_t)2 * P * K * P, 0);   // [0]: what r sends q in slice k at [(r*K + k)*P + q]; [1]: what q expects from r, same index
+    const size_t half = (size_t)P * K * P;
+    for (uint32_t k = 0; k < K; k++) for (uint32_t q = 0; q < P; q++) {
+        m[((size_t)me * K + k) * P + q] = g->send_counts[(size_t)k * P + q];
+        m[half + ((size_t)q * K + k) * P + me] = g->recv_counts[(size_t)k * P + q];
+    }
+    { int st = gt_dist_all_reduce_sum_u64_host(d, m.data(), (uint32_t)m.size()); if (st != GT_OK) return st; }
+    for (size_t i = 0; i < half; i++)
+        GT_REQUIRE(m[i] == m[half + i], GT_ERR_STATE, "exchange plan mismatch: rank %zu sends %llu elements to rank %zu in slice %zu, which expects %llu "
+                   "(were the graphs built from the same edge list, flags and GRAPHTAP_X_SLICES?)", i / ((size_t)K * P), (unsigned long long)m[i], i % P, (i / P) % K,
+                   (unsigned long long)m[half + i]);
+    d->plan_checked = g->serial;
+    return GT_OK;
 }
 
 // block tables of the graph an execute runs on (host + device), the CSR of send positions, the all-reduce words
@@ -966,6 +995,7 @@ static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_
     hipStream_t s = p->stream;
     d->sp_graph = nullptr;   // block tables of the sparse exchange: rebuilt per call (a freed graph's address may come back)
     if (d->loop) { LoopCtx &c = *d->loop; c.peer[d->rank] = LoopPeer{(const char *)p->send, nullptr, g, p->x_bytes, 0}; GT_LOOP_BARRIER(c); }
+    if (!col) { int st = plan_verify(d, g); if (st != GT_OK) return st; }
     (void)gt_program_enable_timing(p, stats != nullptr);
     d->timing = stats != nullptr; d->t_iter = 0; d->t_mode.clear();
     d->list_iters = d->pair_spmspv_iters = d->round_trips = 0;

@@ -391,6 +391,7 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
     GT_REQUIRE(gt_device_count() > 0, GT_ERR_NO_DEVICE, "no HIP device visible: graphtap_amd has no CPU fallback");
     *out = nullptr;
     gt_graph *g = new gt_graph();
+    { static std::atomic<uint64_t> serials{0}; g->serial = ++serials; }
     g->flags = *flags;
     g->info.num_vertices = num_vertices;
     g->info.nrows = num_vertices + 1;                          // mat/graph.hpp:89-90

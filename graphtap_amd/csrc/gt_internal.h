@@ -115,6 +115,7 @@ struct gt_graph {
     struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
     struct gt_tcsc_cf *cf = nullptr;  // the tile in TCSC_CF form, built on first use (tcsc_cf.hip)
     int spmv_variant = 1;        // gt_spmv_variant
+    uint64_t serial = 0;         // unique per built graph (a freed graph's address may come back): what a communicator remembers having checked
 };
 
 // true when the message vector lives in the LOCAL column space filled by an exchange (several ranks, or forced)

@@ -306,6 +306,38 @@ def test_distributed_build_equals_the_replicated_build(gt, name, app, nranks, sl
         for d in dists: L.gt_dist_free(d)
 
 
+def test_mismatched_exchange_plans_are_reported_not_hung(gt, monkeypatch):
+    """Two ranks whose graphs were built from different edge lists: the first execute compares every rank's send counts with
+    every receiver's recv counts (plan_verify) and every rank returns an error -- the grouped send/recv rounds would hang."""
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", "2")
+    c = load_case("rmat10"); nv = c["num_vertices"]
+    hs = (C.c_void_p * 2)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, 2))
+    dists = [C.c_void_p(hs[r]) for r in range(2)]
+    Gs = []
+    for r in range(2):
+        e = c["edges"] if r == 0 else c["edges"][: len(c["edges"]) // 2]      # rank 1 saw half of the list
+        G = gt.Graph(); G.load_edges(e, nv, nv, False, False, False, False, False, gt._2DT_, gt._TCSC_, rank=r, nranks=2); Gs.append(G)
+    ps = [gt.BFS_Program(G, False, False, True, gt._ROW_) for G in Gs]
+    for p in ps: p.root = c["root"]; p.initialize()
+    out = [None, None]
+
+    def work(r):
+        st = gt._lib.ExecStats(); L.gt_set_device(0)
+        rc = L.gt_dist_execute(dists[r], ps[r]._handle(), 0, C.byref(st))
+        out[r] = (rc, L.gt_last_error().decode())
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a rank hangs"
+    assert all(o is not None and o[0] != 0 for o in out), out
+    assert any("exchange plan mismatch" in o[1] for o in out), out
+    for p in ps: p.free()
+    for G in Gs: G.free()
+    for d in dists: L.gt_dist_free(d)
+
+
 def _app(app, args, env_extra):
     exe = os.path.join(ROOT, "apps", "bin", app)
     if not os.path.exists(exe):
