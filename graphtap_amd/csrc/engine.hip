@@ -528,7 +528,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->bu_rows, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+    void *ptrs[] = {p->d_tail, p->bu_rows, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -580,7 +580,8 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
             p->fl_cap = std::max<uint32_t>(std::min<uint32_t>(H, GT_FRONTIER_CAP), 1);   // a list never holds more than the segment's H vertices
             ok = hipMalloc((void **)&p->fl_v[0], (uint64_t)p->fl_cap * 4) == hipSuccess && hipMalloc((void **)&p->fl_v[1], (uint64_t)p->fl_cap * 4) == hipSuccess &&
                  hipMalloc((void **)&p->fl_rows, (uint64_t)p->fl_rows_cap * 4) == hipSuccess &&
-                 hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess;
+                 hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess &&
+                 hipMalloc(&p->d_tail, 64) == hipSuccess;
             if (ok && prm->kind == GT_BFS && !g->flags.directed && !gt_has_exchange(g))   // symmetric graph, whole on one rank: bottom-up steps are possible (kernels.hip)
                 ok = hipMalloc((void **)&p->bu_rows, (uint64_t)std::max<uint32_t>(g->info.nnzrows, 1) * 4) == hipSuccess;
         }
@@ -1145,7 +1146,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     { int st = gt_program_prepare(p, iters); if (st != GT_OK) return st; }   // vp:410-413 + the message width of this run
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
-    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->spmspv_allocs = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
+    p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->tail_iters = 0; p->spmspv_allocs = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
     GT_HIP(hipStreamSynchronize(s));
     const uint32_t val_allocs0 = gt_pb_val_allocs(p->g);
     const size_t ev0 = p->ev.size();
@@ -1176,6 +1177,11 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         samples++;
         if (check) {
             if (active == 0) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
+            if (!p->stationary && !phase_timing) {   // a short list: the rest of the run -- or as much of it as stays short -- in one launch
+                bool conv = false; uint32_t ran = 0;
+                st = gt_tail_try(p, s, &conv, &ran); if (st != GT_OK) return st;
+                if (conv) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
+            }
         } else if (p->iteration >= iters) break;
     }
     GT_HIP(hipStreamSynchronize(s));

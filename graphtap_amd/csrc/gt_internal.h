@@ -191,6 +191,8 @@ struct gt_program {
     bool fl_enabled = false, fl_cur_valid = false, fl_prev_valid = false, fl_rows_valid = false;
     uint32_t fl_cur_n = 0, fl_prev_n = 0;     // host copies of the two list lengths (valid lists only)
     uint32_t list_iters = 0;                  // iterations of the current execute() whose three phases all ran on lists
+    uint32_t tail_iters = 0;                  // ... of them, inside the persistent tail kernel (kernels.hip, gt_tail_try)
+    void *d_tail = nullptr;                   // the tail kernel's result record
     // BOTTOM-UP BFS steps (symmetric graphs): once fewer rows are unreached than vertices are active, the unreached rows look
     // their parent up (minimum id among the neighbours on the current level -- the same value the push sweep leaves in y)
     uint32_t *bu_rows = nullptr;              // [nnzrows] rows of unreached vertices
@@ -291,6 +293,7 @@ int gt_kernels_preload(hipStream_t s);
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
 extern "C" int gt_min_messenger(gt_program *p);      // the messenger of BFS / SSSP / CC, now (engine.hip, inside its extern "C" block; not part of the ABI header)   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
+int gt_tail_try(gt_program *p, hipStream_t s, bool *converged, uint32_t *iterations_run);
 // the SpMSpV over a frontier a driver put into fr_col / fr_val / fr_off (= entry counts) itself (several ranks: the (index, value)
 // pairs its peers sent, dist.hip): y lowered with atomics, the rows it lowered left in fl_rows for the row-list apply
 int gt_spmspv_run_frontier(gt_program *p, uint32_t nact, hipStream_t s);

@@ -362,6 +362,150 @@ __global__ void k_list_frontier(const uint32_t *__restrict__ list, uint32_t n, c
     if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; w++) e += part[w]; if (e) atomicAdd(&out[1], e); }
 }
 
+// ---- the tail of a min program in ONE launch (one rank, converge mode): while the frontier is a short list an iteration is
+// ~20 small launches and a host round trip, 0.17-0.2 ms for microseconds of work. One workgroup runs whole iterations instead --
+// messages of the list's vertices, the SpMSpV over their columns (atomicMin on y, rows de-duplicated through the mark bits),
+// apply of the rows it lowered, the next list -- and loops on the device until nothing changes, or the list or its columns'
+// entries outgrow what one workgroup should do (it then leaves everything as an ordinary iteration would find it).
+constexpr uint32_t TAIL_N = 8192;          // longest list the kernel takes (LDS: 3 x 32 KiB)
+constexpr int TAIL_THREADS = 1024;
+struct TailOut { uint32_t iterations, active, status, cur; unsigned long long changed; };
+enum { TAIL_CONVERGED = 0, TAIL_LIST_GREW = 1, TAIL_ENTRIES = 2, TAIL_MAX_ITERATIONS = 3 };
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // past this CU's L1
+
+template <bool BFS, bool WEIGHTED>
+__global__ void __launch_bounds__(TAIL_THREADS) k_tail(uint32_t *__restrict__ list0, uint32_t *__restrict__ list1, unsigned int *__restrict__ d_fl, int cur, uint32_t list_cap,
+                                                       uint32_t n_cap, uint32_t ent_cap, const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV,
+                                                       const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A,
+                                                       const uint32_t *__restrict__ IR, uint32_t *__restrict__ y, uint32_t *__restrict__ s0, uint32_t *__restrict__ s1,
+                                                       uint8_t *__restrict__ C, uint32_t *__restrict__ marks, uint32_t *__restrict__ rows, uint32_t iteration,
+                                                       uint32_t vid_base, gt_vidmap vm, uint32_t max_it, TailOut *__restrict__ out) {
+    __shared__ uint32_t off[TAIL_N + 1];   // degrees, then exclusive entry offsets of the list's columns
+    __shared__ uint32_t start[TAIL_N];     // first entry of each column
+    __shared__ uint32_t val[TAIL_N];       // its message
+    __shared__ uint32_t wsum[TAIL_THREADS / 64];
+    __shared__ uint32_t s_rows, s_next;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t n = d_fl[cur], done = 0, status = TAIL_CONVERGED;
+    unsigned long long changed = 0;
+    if (tid == 0) { s_rows = 0; s_next = 0; }
+    __syncthreads();
+    for (;;) {
+        if (n > n_cap) { status = TAIL_LIST_GREW; break; }
+        if (done == max_it) { status = TAIL_MAX_ITERATIONS; break; }
+        uint32_t *__restrict__ L = cur ? list1 : list0, *__restrict__ Ln = cur ? list0 : list1;
+        for (uint32_t i = tid; i < TAIL_N; i += TAIL_THREADS) {
+            uint32_t d = 0, st = 0, m = 0;
+            if (i < n) {
+                const uint32_t v = L[i];
+                if (IJ[v] & 2u) { const uint32_t c = JV[v]; st = JA[c]; d = JA[c + 1] - st; }
+                m = BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : ld_agent(s0 + v);   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+            }
+            off[i] = d; start[i] = st; val[i] = m;
+        }
+        __syncthreads();
+        // exclusive scan of the degrees: eight consecutive items per thread, a shuffle scan per wave, the waves' totals through LDS
+        uint32_t loc[TAIL_N / TAIL_THREADS], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < TAIL_N / TAIL_THREADS; j++) { loc[j] = sum; sum += off[tid * (TAIL_N / TAIL_THREADS) + j]; }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (uint32_t w = 0; w < TAIL_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < wave) base += t; total += t; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < TAIL_N / TAIL_THREADS; j++) off[tid * (TAIL_N / TAIL_THREADS) + j] = base + inc - sum + loc[j];
+        if (tid == 0) off[TAIL_N] = total;
+        __syncthreads();
+        if (total > ent_cap) { status = TAIL_ENTRIES; break; }   // nothing has been touched yet: the ordinary path takes this iteration
+        for (uint32_t i = tid; i < n; i += TAIL_THREADS) C[L[i]] = 0;   // the flags of the vertices that were active (apply sets the new ones)
+        // SpMSpV: one thread per entry of the list's columns (vp:1475-1489)
+        for (uint32_t t = tid; t < total; t += TAIL_THREADS) {
+            uint32_t lo = 0, hi = n;   // last i with off[i] <= t
+            while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= t) lo = mid; else hi = mid; }
+            const uint32_t e = start[lo] + (t - off[lo]);
+            const uint32_t r = IA[e];
+            const uint32_t m = WEIGHTED ? val[lo] + A[e] : val[lo];
+            if (m < y[r]) {   // (a stale, higher y only costs an atomic)
+                const uint32_t old = atomicMin(&y[r], m);
+                if (m < old) {
+                    const uint32_t bit = 1u << (r & 31u);
+                    if (!(atomicOr(&marks[r >> 5], bit) & bit)) rows[atomicAdd(&s_rows, 1u)] = r;   // the first to lower the row lists it
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        const uint32_t nrows = s_rows;
+        // apply over the rows that were lowered (the only ones that can change), the next list
+        for (uint32_t i = tid; i < nrows; i += TAIL_THREADS) {
+            const uint32_t r = rows[i];
+            atomicAnd(&marks[r >> 5], ~(1u << (r & 31u)));
+            const uint32_t v = IR[r], yv = ld_agent(y + r);
+            bool c;
+            if (BFS) { c = ld_agent(s1 + v) == GT_INF && yv != GT_INF; if (c) { s1[v] = iteration + done + 1; s0[v] = yv; } }   // bfs.h:65-77
+            else { const uint32_t tmp = ld_agent(s0 + v), nv = yv < tmp ? yv : tmp; c = nv != tmp; if (c) s0[v] = nv; }       // sssp.h:57-65, cc.h:51-55
+            C[v] = c;
+            if (c) { const uint32_t kx = atomicAdd(&s_next, 1u); if (kx < list_cap) Ln[kx] = v; }
+        }
+        __threadfence();
+        __syncthreads();
+        n = s_next; changed += n; done++; cur ^= 1;
+        __syncthreads();
+        if (tid == 0) { s_rows = 0; s_next = 0; }
+        __syncthreads();
+        if (n == 0) { status = TAIL_CONVERGED; break; }
+    }
+    if (tid == 0) {
+        if (done) { d_fl[cur] = n; d_fl[cur ^ 1] = 0; d_fl[2] = 0; }   // (nothing ran: the lists are as the caller left them)
+        out->iterations = done; out->active = n; out->status = status; out->cur = (uint32_t)cur; out->changed = changed;
+    }
+}
+
+}  // namespace
+
+// Called after an apply() that left a short list (converge mode, one rank): runs iterations on the device until the program
+// converges or the frontier outgrows the kernel. *converged: the last apply activated nothing (the caller finishes the run).
+int gt_tail_try(gt_program *p, hipStream_t s, bool *converged, uint32_t *iterations_run) {
+    *converged = false; *iterations_run = 0;
+    const gt_graph *g = p->g;
+    const int enabled = getenv("GRAPHTAP_TAIL_KERNEL") ? atoi(getenv("GRAPHTAP_TAIL_KERNEL")) : 1;   // 0: never
+    const uint32_t n_cap = std::min<uint32_t>(TAIL_N, getenv("GRAPHTAP_TAIL_LIST") ? (uint32_t)atoi(getenv("GRAPHTAP_TAIL_LIST")) : 4096u);   // longest list it takes
+    const uint32_t ent_cap = getenv("GRAPHTAP_TAIL_ENTRIES") ? (uint32_t)atoi(getenv("GRAPHTAP_TAIL_ENTRIES")) : (1u << 17);          // most entries of its columns
+    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    if (senv && atoi(senv) == 0) return GT_OK;   // the sparse paths are switched off: this is one
+    if (!enabled || !p->fl_enabled || !p->fl_cur_valid || gt_has_exchange(g) || p->fl_cur_n == 0 || p->fl_cur_n > n_cap || !p->d_tail) return GT_OK;
+    if (p->semiring != GT_MIN_U32 && p->semiring != GT_MINPLUS_U32) return GT_OK;
+    const uint32_t vb = g->info.rank * g->info.tile_height;
+    const bool bfs = p->prm.kind == GT_BFS, w = p->semiring == GT_MINPLUS_U32;
+    TailOut *out = (TailOut *)p->d_tail;
+#define GT_TAIL_LAUNCH(B, W)                                                                                                              \
+    k_tail<B, W><<<1, TAIL_THREADS, 0, s>>>(p->fl_v[0], p->fl_v[1], p->d_fl, p->fl_cur, p->fl_cap, std::min(n_cap, p->fl_cap), ent_cap, g->IJ, g->JV, g->JA, g->IA, \
+                                            g->A, g->IR, (uint32_t *)p->y, p->s0, p->s1, p->C, (uint32_t *)p->row_mark, p->fl_rows, p->iteration, vb,        \
+                                            gt_vidmap_of(g), 1u << 20, out)
+    if (bfs) GT_TAIL_LAUNCH(true, false); else if (w) GT_TAIL_LAUNCH(false, true); else GT_TAIL_LAUNCH(false, false);
+#undef GT_TAIL_LAUNCH
+    GT_HIP(hipGetLastError());
+    TailOut h{};
+    GT_HIP(hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    if (h.iterations == 0) return GT_OK;   // too many entries in the very first list: nothing was touched
+    p->iteration += h.iterations;
+    p->spmspv_iters += h.iterations; p->list_iters += h.iterations; p->tail_iters += h.iterations;
+    p->fl_prev_valid = false; p->fl_prev_n = 0;   // the messages of the lists in between were never written: the next messenger rewrites x
+    p->x_stale = true; p->x_fresh = false; p->x_deferred = false;
+    p->fl_cur = (int)h.cur; p->fl_cur_n = h.active; p->fl_cur_valid = h.active <= p->fl_cap;
+    p->fl_rows_valid = false;
+    p->last_active = h.active;
+    if (p->prm.kind == GT_BFS) p->bfs_settled += h.changed;
+    *iterations_run = h.iterations;
+    *converged = (h.status == TAIL_CONVERGED);
+    return GT_OK;
+}
+
+namespace {
 }  // namespace
 
 // buffers of the sparse path, sized for frontiers of up to `nact` columns (called at initialize() so that no allocation

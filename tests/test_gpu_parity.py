@@ -992,3 +992,30 @@ def test_no_device_allocation_inside_the_iteration_loop(gt):
         P.root = c["root"]; P.execute(); assert P.stats.allocs_in_execute == 0, app
         P.initialize(); P.execute(); assert P.stats.allocs_in_execute == 0, app
         P.free(); G.free()
+
+
+@pytest.mark.parametrize("caps", [None, ("4", "1000000"), ("4096", "16"), ("64", "256")])
+@pytest.mark.parametrize("scale,seed", [(12, 3), (16, 2)])
+def test_persistent_tail_kernel_is_bit_exact(gt, O, scale, seed, caps, monkeypatch):
+    """The tail of BFS / SSSP / CC in one launch (gt_tail_try: one workgroup loops over whole iterations on the device while the
+    frontier list is short): states and iteration counts equal the oracle's and the run with the kernel switched off -- with
+    the default limits and with tiny ones that make it give up on a long list / on too many entries and come back later."""
+    from graphtap_amd.rmat import rmat_edges
+    nv = 1 << scale
+    w = rmat_edges(scale, 16, seed, weighted=True); e = np.ascontiguousarray(w[:, :2])
+    if caps:
+        monkeypatch.setenv("GRAPHTAP_TAIL_LIST", caps[0]); monkeypatch.setenv("GRAPHTAP_TAIL_ENTRIES", caps[1])
+    for app in ("bfs", "sssp", "cc"):
+        ref = O.run_app(app, w if app == "sssp" else e, nv, root=1)
+        monkeypatch.setenv("GRAPHTAP_TAIL_KERNEL", "1")
+        on = run_min(gt, app, w if app == "sssp" else e, nv, 1)
+        monkeypatch.setenv("GRAPHTAP_TAIL_KERNEL", "0")
+        off = run_min(gt, app, w if app == "sssp" else e, nv, 1)
+        assert on["iterations"] == off["iterations"] == ref["iterations"], app
+        for f in ("parent", "hops", "distance", "label"):
+            if f in ref:
+                assert (on[f] == ref[f]).all() and (off[f] == ref[f]).all(), (app, f)
+        assert on["checksum"] == off["checksum"]
+        assert on["stats"].list_iterations >= off["stats"].list_iterations
+        if caps is None:
+            assert on["stats"].list_iterations > 0
