@@ -439,6 +439,9 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
     const char *env = getenv("GRAPHTAP_SPMV");
+    // default: propagation blocking with f64 messages. pb_f32msg (PageRank's messages rounded to f32 in fixed-count runs: 5e-8 of
+    // relative rank error, tolerance 1e-6) stays opt-in: made the default in round 3 it flipped the sixth decimal of one printed
+    // rank between two layouts (1.425146 / 1.425145) -- the mains must print the reference's lines digit for digit
     g->spmv_variant = (env && strcmp(env, "edge") == 0) ? GT_SPMV_EDGE : (env && strcmp(env, "pb_f32msg") == 0) ? GT_SPMV_PB_F32MSG : GT_SPMV_PB;
     st = gt_layout_build(g);
     if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
@@ -522,7 +525,8 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
     GT_REQUIRE(g && x_dev && y_dev, GT_ERR_INVALID, "null argument");
     int st = x_in_slot_order(g, &x_dev, (semiring == GT_PLUS_F64) ? 8 : 4, (hipStream_t)hip_stream);   // hubs-first layout: the kernels read x by slot
     if (st != GT_OK) return st;
-    return gt_launch_spmv(g, semiring, x_dev, y_dev, (hipStream_t)hip_stream);
+    // the caller's x and y are f64: a bare SpMV keeps f64 messages whatever the graph's variant says about PageRank programs
+    return gt_launch_spmv(g, semiring, x_dev, y_dev, (hipStream_t)hip_stream, false, nullptr, 0, 0, 0xFFFFFFFFu, 0, nullptr, false, true);
 }
 
 // ---- programs

@@ -59,9 +59,12 @@ typedef enum gt_semiring {
 /* implementations of the generalized SpMV over a tile-row (same results, different HBM traffic) */
 typedef enum gt_spmv_variant {
     GT_SPMV_EDGE = 0, /* one lane per stored entry, device atomics on y (correctness baseline)      */
-    GT_SPMV_PB = 1,   /* propagation blocking: LDS-staged messages + LDS row-bin accumulators (default) */
-    GT_SPMV_PB_F32MSG = 2 /* same, PageRank messages rounded to f32 in flight (sums, ranks and y stay f64);
-                             halves the value stream; integer semirings are unaffected */
+    GT_SPMV_PB = 1,   /* propagation blocking: LDS-staged messages + LDS row-bin accumulators; f64 messages everywhere (default) */
+    GT_SPMV_PB_F32MSG = 2 /* same, a PageRank PROGRAM's messages rounded to f32 in flight in fixed-count runs (sums, ranks and y
+                             stay f64; max relative rank error 5e-8 against the fp64 oracle, tolerance 1e-6); converge mode
+                             (gt_program_prepare) and the bare gt_spmv keep f64 messages; halves the value stream; integer
+                             semirings are unaffected. Opt-in (GRAPHTAP_SPMV=pb_f32msg; bench.py's default): as the default it flipped the
+                             sixth printed decimal of a rank between two layouts, and the mains print the reference's lines */
 } gt_spmv_variant;
 
 typedef struct gt_graph gt_graph;     /* replaces Graph<> + Matrix<> + tile compressors */
@@ -222,7 +225,7 @@ int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_
                                uint32_t num_vertices, const gt_graph_flags *flags);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
 /* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
- * GT_SPMV_PB, or GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=edge at build time). */
+ * GT_SPMV_PB; GT_SPMV_PB_F32MSG / GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=pb_f32msg / edge at build time). */
 int gt_graph_select_spmv(gt_graph *g, int variant);
 int gt_graph_tile(const gt_graph *g, gt_tile_arrays *arrays);
 /* Builds the TCSC_CF form on first use (Matrix::init_tcsc_cf, mat/matrix.hpp:1370-1403); the arrays live until gt_graph_free. */
