@@ -10,8 +10,9 @@
 //            Two kinds of windows (x is laid out HUBS FIRST on a single rank, gt_layout_build):
 //              DENSE  windows (W = 16383 slots, the columns of largest out-degree): consecutive entries of the same row
 //                     are PRE-AGGREGATED (+ or min) over whole 256-entry groups before they leave the chip -- a lane
-//                     combines its quad in registers, lanes meet through LDS atomics on the wave's staging row -- and
-//                     the (value, slot) pairs of a group are stored as coalesced runs (k_pb_scatter);
+//                     combines its quad in registers, what a quad leaves open reaches the lane that holds the stretch's end
+//                     through one segmented DPP scan whose flags are a scalar mask -- and the outputs of a group leave in
+//                     stores of 64 consecutive slots (staged through an LDS row; the min kernels store directly) (k_pb_scatter);
 //              SPARSE windows (WS = 16384 slots, low-degree columns, nothing to aggregate): one slot per entry, the
 //                     slot is the entry's position: four values per lane stored with one 16-byte store (same kernel, other branch).
 //   phase 2  "gather"    one workgroup per ROW BIN (R = 16384 consecutive compressed rows; heavy
@@ -33,7 +34,8 @@
 //   WT[v]    u8 / u16 / u32 (the narrowest the largest weight fits) weights in v-order (min-plus only)
 //   G[g]     32 B per 256 entries of the v-order: the k-slot of lane 0's first output and, for the first six
 //                 run heads of the group, (k-slot of the run - outputs of the group before the head), so that no
-//                 load of phase 1 depends on another load and a lane gets its slots with one ds_bpermute
+//                 load of phase 1 depends on another load; lane j of a wave holds dword j & 7 and the run constants are
+//                 read off it with scalar readlanes (the direct-store form: one ds_bpermute per lane)
 //   KSTART[s]     k-slot where run s starts - outputs of the whole v-order before it (groups with 7+ run heads)
 // HBM traffic per entry per SpMV: 2 + 0.125 (phase 1 in) + (F + F + 2) / D (value stream out and back, LROW),
 // D = entries per output, F = bytes of a message in flight.
