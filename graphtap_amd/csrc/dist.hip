@@ -336,6 +336,7 @@ int collect_times(gt_dist *d, uint32_t iterations, bool comm_ticks) {
     return GT_OK;
 }
 
+int sync_deadline(gt_dist *d, hipStream_t s, const char *what);
 int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s) {
     if (d->loop) {
         LoopCtx &c = *d->loop;
@@ -353,8 +354,7 @@ int dist_all_reduce_words(gt_dist *d, uint64_t *v, uint32_t count, hipStream_t s
     GT_HIP(hipMemcpyAsync(d->d_word, v, (size_t)count * 8, hipMemcpyHostToDevice, s));
     GT_NCCL(rccl()->AllReduce(d->d_word, d->d_word, count, ncclUint64, ncclSum, d->comm, s));
     GT_HIP(hipMemcpyAsync(v, d->d_word, (size_t)count * 8, hipMemcpyDeviceToHost, s));
-    GT_HIP(hipStreamSynchronize(s));
-    return GT_OK;
+    return sync_deadline(d, s, "an all-reduce of 8-byte words");
 }
 
 static inline bool block_sparse(uint32_t count, uint32_t len) { return len != 0 && 2ull * count < len; }   // pairs cost 8 B, a dense message 4
