@@ -1012,7 +1012,7 @@ static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_
         int st = tick(d, T_START, s); if (st != GT_OK) return st;
         p->pack_deferred = !d->loop && !col && p->stationary && K > 1;   // stationary programs send dense blocks: packing and sending overlap slice by slice
         st = gt_program_scatter_gather(p); if (st != GT_OK) { p->pack_deferred = false; return st; }
-        if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; }
+        if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; p->pr_state = gt_pr_state_mode(p, iters, check); }
         st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
         if (!col && !p->converged) {
             st = exchange_issue(d, p, s); p->pack_deferred = false; if (st != GT_OK) return st;

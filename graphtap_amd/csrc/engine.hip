@@ -123,7 +123,7 @@ template <class TX>
 __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restrict__ R2C, uint32_t nr,
                                double *__restrict__ rank_c, const uint32_t *__restrict__ deg_c, uint8_t *__restrict__ C_c,
                                TX *__restrict__ x, double alpha, double tol, int cf, int last,
-                               unsigned long long *d_active, const uint32_t *__restrict__ bins, uint32_t nbins_listed) {
+                               unsigned long long *d_active, const uint32_t *__restrict__ bins, uint32_t nbins_listed, int state) {
     // bins == null: every row. Otherwise only the rows of the listed row bins (the ones phase 2 did not apply itself, pb.hip).
     constexpr uint32_t RB = GT_PB_ROW_BIN_BITS, RR = 1u << RB;
     const uint64_t n = bins ? (uint64_t)nbins_listed << RB : nr;
@@ -136,12 +136,14 @@ __global__ void k_pr_apply_msg(double *__restrict__ y, const uint32_t *__restric
         const double yr = y[r];
         y[r] = 0.0;
         if (cf && source && !last) continue;   // vp:1671-1691
-        const double tmp = rank_c[r];
         const double nv = alpha + (1.0 - alpha) * yr;
-        rank_c[r] = nv;
-        const uint8_t ch = fabs(nv - tmp) > tol;
-        C_c[r] = ch;
-        act += (ch && !(cf && source));
+        const double tmp = state == 0 ? rank_c[r] : 0.0;   // state: gt_program::pr_state (1, 2: nobody can see this iteration's rank / changed flag)
+        if (state != 2) rank_c[r] = nv;
+        if (state == 0) {
+            const uint8_t ch = fabs(nv - tmp) > tol;
+            C_c[r] = ch;
+            act += (ch && !(cf && source));
+        }
         if (!source) { const uint32_t d = deg_c[r]; x[c] = (TX)(d ? nv / (double)d : 0.0); }
     }
     count_active(act, d_active);
@@ -846,7 +848,7 @@ static bool fused_epilogue(gt_program *p, gt_pr_epilogue *epi) {
     if (!(p->fuse_armed && p->prm.kind == GT_PR && g->spmv_variant != GT_SPMV_EDGE && g->pb != nullptr)) return false;
     const bool cf = (p->prm.compression == GT_TCSC_CF);
     *epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, gt_row_slot(g), p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
-                          cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr};
+                          cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr, p->pr_state};
     return true;
 }
 
@@ -1033,11 +1035,12 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
             const uint64_t nwork = list ? (uint64_t)nlist << GT_PB_ROW_BIN_BITS : nr;
             if (nwork && p->x_f32)
                 k_pr_apply_msg<float><<<grid_for(nwork), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
-                                                                      p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist);
+                                                                      p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist, p->pr_state);
             else if (nwork)
                 k_pr_apply_msg<double><<<grid_for(nwork), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (double *)xm,
-                                                                       p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist);
+                                                                       p->prm.alpha, p->prm.tol, cf, last, d_active, list, nlist, p->pr_state);
             p->v_stale = true; p->x_fresh = true; p->y_clean = true;
+            p->pr_state = 0;   // the loop that owns the iterations sets it before every combine; a caller stepping by hand gets the full applicator
             break;
         }
         default: {   // BFS, SSSP, CC
@@ -1173,6 +1176,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         st = lap(tp, t_sg, q_sg); if (st != GT_OK) return st;
         // PageRank: apply follows combine at once, so phase 2 may apply the rows whose sums it completes (pb.hip)
         p->fuse_armed = fuse_apply && p->prm.kind == GT_PR && !p->converged; p->fuse_iters = iters; p->fuse_count = check; p->cf_hint = true;
+        p->pr_state = gt_pr_state_mode(p, iters, check);
         st = combine_impl(p, stats != nullptr, 0, p->g->info.x_slices); if (st != GT_OK) return st;
         st = lap(tp, t_cb, q_cb); if (st != GT_OK) return st;
         uint64_t active = 0;

@@ -210,6 +210,11 @@ struct gt_program {
     bool fuse_armed = false, fused = false;   // armed before combine; fused = the combine of this iteration did it
     uint32_t fuse_iters = 0;
     bool fuse_count = false;
+    // PageRank, fixed iteration count, the loop owned by the library (gt_program_execute / gt_dist_execute): rank (pr.h:43-47) does
+    // not depend on the previous rank, so an iteration that is neither the last nor the one before it only has to produce the
+    // next messages -- the stores of rank / C it would make are overwritten before anybody can read them. 0 = full applicator,
+    // 1 = writes rank (the last iteration compares against it), 2 = messages only. Set per iteration by gt_pr_state_mode().
+    int pr_state = 0;
     std::vector<hipStream_t> slice_streams;
     std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
 };
@@ -239,7 +244,15 @@ struct gt_pr_epilogue {
     void *x; int x_f32;
     double alpha, tol; int cf, last;
     unsigned long long *d_active;
+    int state;   // gt_program::pr_state: 0 = full, 1 = no read of the old rank and no changed flag, 2 = messages only
 };
+// which of the three the iteration about to run may use (GRAPHTAP_PR_LEAN_STATE=0: always the full one)
+static inline int gt_pr_state_mode(const gt_program *p, uint32_t iters, bool check) {
+    const char *e = getenv("GRAPHTAP_PR_LEAN_STATE");   // read per call: the tests run both ways in one process
+    const bool lean = !(e && atoi(e) == 0);
+    if (!lean || p->prm.kind != GT_PR || check || iters == 0 || p->iteration + 1 >= iters) return 0;
+    return p->iteration + 2 == iters ? 1 : 2;
+}
 const uint8_t *gt_pb_bin_single(const gt_graph *g);   // [row bins] 1 = one phase-2 workgroup owns the bin
 const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n);   // the bins that are NOT single (device list): the only rows the apply kernel visits after a fused combine
 uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins

@@ -491,7 +491,7 @@ template <> struct Msg<uint32_t, uint32_t> { static __device__ __forceinline__ u
 #ifndef GT_PB_NT
 #define GT_PB_NT 2   // bit 0: loads of phase 1, bit 1: loads of phase 2, bit 2: stores of the value stream (A/B below)
 #endif
-constexpr bool NT_P1 = (GT_PB_NT & 1) != 0, NT_P2 = (GT_PB_NT & 2) != 0, NT_ST = (GT_PB_NT & 4) != 0;
+constexpr bool NT_P1 = (GT_PB_NT & 1) != 0, NT_P2 = (GT_PB_NT & 2) != 0, NT_ST = (GT_PB_NT & 4) != 0, NT_EPI = (GT_PB_NT & 8) != 0;   // bit 3: the row -> slot map and the degrees in phase 2's flush
 typedef uint32_t gt_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t gt_u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT, class S> __device__ __forceinline__ S ld_stream(const S *__restrict__ p) {
@@ -608,6 +608,33 @@ template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry_masked
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
     TV v = t;
+#ifdef GT_P1_SCAN_NF   // the flags kept COMPLEMENTED (lanes still open): NF' = NF & ((NF << d) | ~pattern) -- shift, or, and per step, no s_not
+    {
+        uint64_t NF = ~F;
+#define GT_NSEG_STEP(CTRL, D, NPAT)                                                \
+        {                                                                          \
+            const TV vs = dpp_get<CTRL, 0xf, TV>(v, neutral);                      \
+            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;         \
+            NF &= (NF << D) | (NPAT);                                              \
+        }
+        GT_NSEG_STEP(0x111, 1, 0x0001000100010001ull)
+        GT_NSEG_STEP(0x112, 2, 0x0003000300030003ull)
+        GT_NSEG_STEP(0x114, 4, 0x000F000F000F000Full)
+        GT_NSEG_STEP(0x118, 8, 0x00FF00FF00FF00FFull)
+#undef GT_NSEG_STEP
+        {   // row_bcast:15 into rows 1, 3: a row stays open for it while the lane that feeds it (15 / 47) is
+            const TV vs = dpp_get<0x142, 0xa, TV>(v, neutral);
+            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;
+            const uint32_t lo = (uint32_t)NF, hi = (uint32_t)(NF >> 32);
+            NF = ((uint64_t)((hi & 0x8000u) ? hi : (hi & 0xFFFFu)) << 32) | ((lo & 0x8000u) ? lo : (lo & 0xFFFFu));
+        }
+        {
+            const TV vs = dpp_get<0x143, 0xc, TV>(v, neutral);
+            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;
+        }
+        return dpp_get<0x138, 0xf, TV>(v, neutral);
+    }
+#endif
 #define GT_MSEG_STEP(CTRL, RM, NEXT_F)                                             \
     {                                                                              \
         const TV vs = dpp_get<CTRL, RM, TV>(v, neutral);                           \
@@ -716,6 +743,22 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const TV a3 = e2 ? v3 : comb(a2, v3);
             // what the quad leaves open for the lanes above: everything when it holds no end, else what follows its last end
             const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
+#if defined(GT_P1_SBURN) || defined(GT_P1_VBURN)   // experiment: extra dependent scalar / vector instructions per group (which issue port binds phase 1?)
+            {
+#ifdef GT_P1_SBURN
+                uint32_t sb = wave;
+#pragma unroll
+                for (int b = 0; b < GT_P1_SBURN; b++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sb) : : "scc");
+                if (sb == 0xdeadbeefu) stage[wave][0] = (TV)0;
+#endif
+#ifdef GT_P1_VBURN
+                uint32_t vb = lane;
+#pragma unroll
+                for (int b = 0; b < GT_P1_VBURN; b++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vb));
+                if (vb == 0xdeadbeefu) stage[wave][0] = (TV)0;
+#endif
+            }
+#endif
             // the quad's first end also closes what the lanes below left open
             if constexpr (!STAGED) {   // every lane stores its outputs itself: the k-slots of a wave's outputs are consecutive
                 const uint32_t k0 = i0 + run_delta(lane, head, gw[u], KSTART);   // + the constant of the lane's run
@@ -813,9 +856,9 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                 for (int u = 0; u < EB; u++) {
                     const uint32_t i = i0 + u * P2_THREADS, r = row0 + i;
                     live[u] = i < rn;
-                    c[u] = live[u] ? epi.R2X[r] : 0xFFFFFFFFu;
-                    tmp[u] = live[u] ? epi.rank_c[r] : 0.0;
-                    d[u] = live[u] ? epi.deg_c[r] : 0u;
+                    c[u] = live[u] ? ld_stream<NT_EPI>(epi.R2X + r) : 0xFFFFFFFFu;
+                    tmp[u] = (live[u] && epi.state == 0) ? epi.rank_c[r] : 0.0;
+                    d[u] = live[u] ? ld_stream<NT_EPI>(epi.deg_c + r) : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < EB; u++) {
@@ -823,10 +866,12 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                     const bool source = (c[u] == 0xFFFFFFFFu);
                     if (!live[u] || (epi.cf && source && !epi.last)) continue;   // vp:1671-1691
                     const double nv = epi.alpha + (1.0 - epi.alpha) * (double)acc[i];
-                    epi.rank_c[r] = nv;
-                    const uint8_t ch = fabs(nv - tmp[u]) > epi.tol;
-                    epi.C_c[r] = ch;
-                    act += (ch && !(epi.cf && source));
+                    if (epi.state != 2) epi.rank_c[r] = nv;
+                    if (epi.state == 0) {   // (1, 2: an iteration whose rank / changed flag nobody can see -- gt_internal.h, pr_state)
+                        const uint8_t ch = fabs(nv - tmp[u]) > epi.tol;
+                        epi.C_c[r] = ch;
+                        act += (ch && !(epi.cf && source));
+                    }
                     if (!source) xo[c[u]] = (TX)(d[u] ? nv / (double)d[u] : 0.0);
                 }
             }

@@ -272,6 +272,39 @@ def test_pagerank_matches_reference(gt, name, iters, known_answers):
     assert r["checksum"][1] == ka["reachable"] and abs(r["checksum"][0] - ka["checksum"]) <= 1  # truncating sum: order-sensitive by 1 ulp cases
 
 
+@pytest.mark.parametrize("variant", ["pb", "pb_f32msg", "edge"])
+@pytest.mark.parametrize("name", ["rmat10", "rmat12"])
+def test_pagerank_lean_iterations_leave_the_full_state(gt, name, variant, monkeypatch):
+    """A fixed-count PageRank run owned by the library skips, in every iteration but the last two, the loads and stores of
+    vertex state that nobody can observe (rank does not depend on the previous rank, pr.h:43-47; gt_internal.h pr_state).
+    After execute(n) every field -- rank AND the changed flags of the last iteration (vp:1671-1691) -- equals what the full
+    applicator (GRAPHTAP_PR_LEAN_STATE=0) leaves, also when a second execute continues the run."""
+    c = load_case(name); nv = c["num_vertices"]
+    monkeypatch.setenv("GRAPHTAP_SPMV", variant)
+
+    def run(lean, plan):
+        monkeypatch.setenv("GRAPHTAP_PR_LEAN_STATE", "1" if lean else "0")
+        G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+        V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+        P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V)
+        out = []
+        for iters in plan:
+            P.execute(iters)
+            H = G.info.tile_height
+            act = np.zeros(H, np.uint8)
+            gt._lib.check(gt._lib.lib().gt_program_copy_state(P._handle(), gt._lib.GT_F_ACTIVE, act.ctypes.data_as(C.c_void_p), H))
+            out.append((P.iteration, P.V["rank"].copy(), act, P.checksum(out=None)))
+        P.free(); V.free(); G.free()
+        return out
+
+    for plan in ([1], [2], [3], [7], [3, 8], [2, 3, 4]):
+        full, lean = run(False, plan), run(True, plan)
+        for (it0, r0, a0, k0), (it1, r1, a1, k1) in zip(full, lean):
+            assert it0 == it1 and k0[1] == k1[1] and abs(k0[0] - k1[0]) <= 1
+            assert (np.abs(r0 - r1) <= 1e-12 * np.abs(r0)).all()   # same arithmetic; the LDS atomics' order is free
+            assert (a0 == a1).all()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_pagerank_converge_mode_matches_reference(gt, name, known_answers):
     c = load_case(name); n = c["num_vertices"] + 1
