@@ -250,10 +250,17 @@ def main():
         return 4 * i.nnz_local + 4 * (ncols + 1) + fx * ncols + 8 * i.nnzrows
     b_spmv = b_spmv_of(args.spmv)
     # one rank: the SpMV launch pair also runs PageRank's applicator + next messenger for the rows of the bins one
-    # phase-2 workgroup owns; its compulsory bytes per such row: rank read + write, changed flag, degree,
-    # row->column map, message = 8 + 8 + 1 + 4 + 4 + (4 | 8). Reported beside the headline fraction, never inside it.
+    # phase-2 workgroup owns; its compulsory bytes per such row with the full applicator: rank read + write, changed
+    # flag, degree, row->column map, message = 8 + 8 + 1 + 4 + 4 + (4 | 8). Reported beside the headline fraction, never inside it.
+    # Since round 3 a fixed-count run writes rank / changed flags only where somebody can see them (gt_internal.h, pr_state): the last
+    # iteration is the full applicator, the one before it writes rank (8 + 4 + 4 + Fx), the others only the next messages
+    # (degree, row->slot map, message = 4 + 4 + Fx); the figure below is the mean over the K timed steps.
     fused_rows = int(VR.stats.fused_apply_rows) if not G.exchange else 0
-    b_fused = fused_rows * (25 + (4 if args.spmv == "pb_f32msg" else 8))
+    fx_b = 4 if args.spmv == "pb_f32msg" else 8
+    lean = os.environ.get("GRAPHTAP_PR_LEAN_STATE", "1") != "0"
+    K = args.steps
+    per_row = (25 + fx_b) if not lean else ((25 + fx_b) + (16 + fx_b) * min(1, K - 1) + (8 + fx_b) * max(0, K - 2)) / K
+    b_fused = fused_rows * per_row
     t = torch.tensor([dt, kernel_ms, float(b_spmv), float(b_fused)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,7 +314,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(G.nnzrows_global), "nnzcols": int(i.nnzcols_global),
-                   "spmv": args.spmv, "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if dist_on else "single tile",
+                   "spmv": args.spmv, "applicator": "rank / changed flags stored by the last two iterations only (dead stores elided; GRAPHTAP_PR_LEAN_STATE=0: every iteration)" if lean else "full state every iteration",
+                   "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if dist_on else "single tile",
                    "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if dist_on else "C++ gt_program_execute",
                    "ingress_s": round(t_ingress, 3), "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
         "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter* + k_pb_gather<double,double> (one SpMV = this launch group)",

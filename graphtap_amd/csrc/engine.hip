@@ -534,7 +534,7 @@ int gt_spmv(const gt_graph *g, int semiring, const void *x_dev, void *y_dev, voi
 // ---- programs
 int gt_program_free(gt_program *p) {
     if (!p) return GT_OK;
-    void *ptrs[] = {p->d_tail, p->bu_rows, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
+    void *ptrs[] = {p->d_tail, p->bu_first, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -589,7 +589,12 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
                  hipMalloc((void **)&p->row_mark, ((uint64_t)g->info.nnzrows / 32 + 1) * 4) == hipSuccess && hipMalloc((void **)&p->d_fl, 4 * sizeof(unsigned int)) == hipSuccess &&
                  hipMalloc(&p->d_tail, 64) == hipSuccess;
             if (ok && prm->kind == GT_BFS && !g->flags.directed && !gt_has_exchange(g))   // symmetric graph, whole on one rank: bottom-up steps are possible (kernels.hip)
-                ok = hipMalloc((void **)&p->bu_rows, (uint64_t)std::max<uint32_t>(g->info.nnzrows, 1) * 4) == hipSuccess;
+            {   // + one bit per row, written 4096 rows at a time (k_bu_collect)
+                const uint64_t nrw = std::max<uint32_t>(g->info.nnzrows, 1), bit_words = ((nrw + 4095) / 4096) * 128;
+                ok = hipMalloc((void **)&p->bu_rows, (6 * nrw + bit_words) * 4) == hipSuccess;   // (the quads first: 16-byte aligned)
+                if (ok) { p->bu_first = p->bu_rows; p->bu_rows = p->bu_first + 4 * nrw; p->bu_long = p->bu_rows + nrw; p->bu_bits = p->bu_long + nrw; }
+                if (ok && gt_bu_first_neighbours(g, p->bu_first, 0) != GT_OK) ok = false;
+            }
         }
     }
     if (ok && prm->kind == GT_PR) {

@@ -196,6 +196,9 @@ struct gt_program {
     // BOTTOM-UP BFS steps (symmetric graphs): once fewer rows are unreached than vertices are active, the unreached rows look
     // their parent up (minimum id among the neighbours on the current level -- the same value the push sweep leaves in y)
     uint32_t *bu_rows = nullptr;              // [nnzrows] rows of unreached vertices
+    uint32_t *bu_bits = nullptr;              // bitmap over the rows: on the current level (same allocation, behind bu_rows)
+    uint32_t *bu_long = nullptr;              // [nnzrows] positions in bu_rows of the rows whose first probes found nothing (same allocation)
+    uint32_t *bu_first = nullptr;             // [4 nnzrows] the first four entries of every row's column (same allocation, 16-byte aligned; initialize)
     uint64_t bfs_settled = 0;                 // rows reached so far (host estimate from the active counts)
     uint32_t bottom_up_iters = 0;
     // a bottom-up step reads no messages: scatter_gather() defers the messenger when such a step is likely, combine runs it
@@ -303,6 +306,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done);
 // the messenger over the frontier lists: resets the slots of the previous frontier, writes the messages of the current one
 int gt_frontier_messages(gt_program *p, hipStream_t s);
 int gt_kernels_preload(hipStream_t s);
+int gt_bu_first_neighbours(const gt_graph *g, uint32_t *FN, hipStream_t s);   // fills gt_program::bu_first
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
 extern "C" int gt_min_messenger(gt_program *p);      // the messenger of BFS / SSSP / CC, now (engine.hip, inside its extern "C" block; not part of the ABI header)   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);

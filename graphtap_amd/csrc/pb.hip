@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
             // EB rows per thread and trip, every load of the trip issued before the first store: the flush of a 16 384-row bin is
             // 16 dependent round trips per thread otherwise (latency-bound for ~30 % of the workgroup's life)
 #ifndef GT_P2_EB
-#define GT_P2_EB 8
+#define GT_P2_EB 16   // with the lean applicator (two loads per row) a whole 16 384-row bin in one trip: phase 2 0.571 -> 0.557 ms (A/B, gpurun_out/s3/ab1.txt); 4: +2 %
 #endif
             constexpr int EB = GT_P2_EB;
             for (uint32_t i0 = threadIdx.x; i0 < rn; i0 += EB * P2_THREADS) {

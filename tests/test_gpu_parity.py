@@ -440,14 +440,19 @@ def test_frontier_lists_are_bit_exact(gt, O, lists, spmspv, known_answers, monke
     if lists == "1": assert got["stats"].list_iterations > 0   # the tail iterations of CC
 
 
+@pytest.mark.parametrize("early", [None, "0"])
 @pytest.mark.parametrize("mode", ["1", "0", None])
-def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, known_answers, monkeypatch):
+def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, early, known_answers, monkeypatch):
     """BFS on a symmetric graph (apps/bfs.cpp loads with directed = false) may run an iteration bottom-up: the unreached rows
     look at ALL their neighbours and take the minimum id among those on the current level -- what the push sweep's
     min-combiner (bfs.h:61-63) leaves in y. Parents, hops and iteration counts must be the reference's with the step forced
-    on every iteration (=1), forbidden (=0) and chosen by size (unset); a directed graph never takes it."""
+    on every iteration (=1), forbidden (=0) and chosen by size (unset); a directed graph never takes it. By default a row stops
+    at its FIRST neighbour on the level (entries ascend by row, rows by vertex id: the first hit is the minimum), which also lets
+    the step run against a large frontier; GRAPHTAP_BFS_BU_EARLY=0 is the form that looks at every neighbour."""
     from graphtap_amd.rmat import rmat_edges
     if mode is not None: monkeypatch.setenv("GRAPHTAP_BFS_BOTTOM_UP", mode)
+    if early is not None: monkeypatch.setenv("GRAPHTAP_BFS_BU_EARLY", early)
+    if early == "0" and mode == "0": pytest.skip("no bottom-up step at all: covered by the default form")
     for name in CASES:
         c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
         for root, tag in ((c["root"], ""), (0, "0")) if c["root"] != 0 else ((0, ""),):
