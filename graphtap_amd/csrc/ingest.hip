@@ -202,10 +202,11 @@ __device__ __forceinline__ uint32_t local_col(const BlockTab *__restrict__ tab, 
 // sort keys of the needed columns / of the (destination, owned column) pairs: (block, entries descending); the radix sort is
 // stable and the items arrive in ascending column order
 __global__ void k_need_keys(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ Sneed, uint64_t span, const uint32_t *__restrict__ Scol,
-                            uint32_t H, uint32_t T, uint32_t p, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+                            uint32_t H, uint32_t T, uint32_t p, uint32_t hub_min, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
     for (uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; c < span; c += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t n = cnt[c];
+        uint32_t n = cnt[c];
         if (!n) continue;
+        if (n < hub_min) n = 0;   // the tail of a block: one class, in column order (exchange_hub_min below)
         const uint32_t seg = (uint32_t)(c / H), j = Scol[c] - Scol[(uint64_t)seg * H], k = j / T;
         const uint32_t o = Sneed[c];
         key[o] = ((uint64_t)(k * p + seg) << 32) | (0xFFFFFFFFu - n);
@@ -213,11 +214,12 @@ __global__ void k_need_keys(const uint32_t *__restrict__ cnt, const uint32_t *__
     }
 }
 __global__ void k_by_keys(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ Sby, uint32_t H, uint32_t T, uint32_t p,
-                          const uint32_t *__restrict__ Scol, uint32_t col_lo, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+                          const uint32_t *__restrict__ Scol, uint32_t col_lo, uint32_t hub_min, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
     const uint64_t n_all = (uint64_t)p * H;
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < n_all; t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t n = cnt[t];
+        uint32_t n = cnt[t];
         if (!n) continue;
+        if (n < hub_min) n = 0;
         const uint32_t d = (uint32_t)(t / H), i = (uint32_t)(t - (uint64_t)d * H);
         const uint32_t j = Scol[col_lo + i] - Scol[col_lo], k = j / T;
         const uint32_t o = Sby[t];
@@ -552,6 +554,13 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_d
         // (destination, owned column) pairs; block b = k * p + q starts where the blocks before it (in b order) end
         {
             const uint32_t nblk = K * p;
+            // Inside a block the columns with at least `hub_min` entries in the receiving tile-row come first, by descending count (the
+            // receiver's hub windows); ALL the others follow as one class in column order. Sorted by count all the way down, a block was
+            // ~20 count classes, each a sparse sweep of the sender's gather over its whole segment buffer (k_pack_send: 12.6 M gathers
+            // pulling ~1.6 GB of lines, 0.08 ms per step on a tile-row of 8 of R-MAT-26); the receiver gains nothing from an order among
+            // columns that hold one to a few entries. Both sides derive the order from the same counts. GRAPHTAP_EXCHANGE_HUB_MIN.
+            const char *hm = getenv("GRAPHTAP_EXCHANGE_HUB_MIN");
+            const uint32_t hub_min = hm ? (uint32_t)atoi(hm) : 8u;
             std::vector<uint32_t> start_me(nblk + 1, 0), start_by(nblk + 1, 0);
             for (uint32_t b = 0; b < nblk; b++) {   // b = kk * p + q, the order of the sort key
                 start_me[b + 1] = start_me[b] + (sneed_at[b + p] - sneed_at[b]);
@@ -572,8 +581,8 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_d
             for (int side = 0; side < 2; side++) {
                 const uint32_t n = side ? n_by : n_me;
                 if (!n) continue;
-                if (side == 0) k_need_keys<<<grid_for(span), TPB, 0, s>>>(needme.as<uint32_t>(), Sneed.as<uint32_t>(), span, Scol.as<uint32_t>(), H, T, p, k1.as<uint64_t>(), v1.as<uint32_t>());
-                else k_by_keys<<<grid_for(span), TPB, 0, s>>>(needby.as<uint32_t>(), Sby.as<uint32_t>(), H, T, p, Scol.as<uint32_t>(), row_lo, k1.as<uint64_t>(), v1.as<uint32_t>());
+                if (side == 0) k_need_keys<<<grid_for(span), TPB, 0, s>>>(needme.as<uint32_t>(), Sneed.as<uint32_t>(), span, Scol.as<uint32_t>(), H, T, p, hub_min, k1.as<uint64_t>(), v1.as<uint32_t>());
+                else k_by_keys<<<grid_for(span), TPB, 0, s>>>(needby.as<uint32_t>(), Sby.as<uint32_t>(), H, T, p, Scol.as<uint32_t>(), row_lo, hub_min, k1.as<uint64_t>(), v1.as<uint32_t>());
                 hipcub::DoubleBuffer<uint64_t> dk(k1.as<uint64_t>(), k2.as<uint64_t>());
                 hipcub::DoubleBuffer<uint32_t> dv(v1.as<uint32_t>(), v2.as<uint32_t>());
                 size_t tb2 = tb;

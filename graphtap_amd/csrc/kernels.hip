@@ -691,7 +691,7 @@ static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
     constexpr uint32_t LPR = 16;
     const uint64_t per_row = fe ? std::max<uint64_t>(LPR, nnz / fe) : ~0ull;
     const bool few = entries <= nnz / 8, heavy = early && fe != 0 && per_row < nnz && (uint64_t)n * per_row * 2 <= nnz;
-    if (dbg) fprintf(stderr, "[bfs] iteration %u: %u unreached rows hold %llu entries, the frontier's columns %llu: %s\n", p->iteration, n, entries, fe,
+    if (dbg) fprintf(stderr, "[bfs] iteration %u: %u unreached rows hold %llu entries, the frontier's columns %llu: %s\n", p->iteration, n, (unsigned long long)entries, (unsigned long long)fe,
                      (mode == 1 || few || heavy) ? (early ? "bottom-up step (first hit)" : "bottom-up step") : "push sweep");
     if (mode != 1 && !few && !heavy) return GT_OK;   // the push sweep is the cheaper one
     // the rows that found a parent go to apply as a list (position for position, ~0u for the others) -- unless they are a large
