@@ -1110,7 +1110,7 @@ static int apply_finish(gt_program *p, bool counted, unsigned long long h, bool 
     if (p->fl_enabled && !p->stationary) {   // the list of the vertices this apply changed becomes the current frontier
         p->fl_prev_valid = p->fl_cur_valid; p->fl_prev_n = p->fl_cur_n;
         p->fl_cur ^= 1;
-        p->fl_cur_valid = counted && p->last_active <= p->fl_cap;
+        p->fl_cur_valid = counted && p->last_active <= p->fl_cap && (!list_from_flags || gt_frontier_list_worth(p, p->last_active));   // (a list the row-list apply appended exists already)
         p->fl_cur_n = p->fl_cur_valid ? (uint32_t)p->last_active : 0;
         if (p->fl_cur_valid && list_from_flags && nr && p->fl_cur_n)   // a full apply that changed few: collect them
             k_list_from_flags<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + 4095) / 4096, 4096), TPB, 0, s>>>(g->IR, nr, p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur, p->fl_cap);
