@@ -223,7 +223,9 @@ struct gt_program {
 };
 
 #define GT_FRONTIER_CAP (1u << 24)   // longest frontier kept as a list
+#ifndef GT_PB_ROW_BIN_BITS
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
+#endif
 #ifndef GT_PB_WINDOW
 #define GT_PB_WINDOW 16383u   // columns per DENSE phase-1 window (pb.hip): LDS slot GT_PB_WINDOW holds the neutral message that pad
                               // entries read, and a column offset (or the pad) must fit 14 bits; slice widths are multiples of it

@@ -603,38 +603,14 @@ template <int CTRL, int ROW_MASK, class TV> __device__ __forceinline__ TV dpp_ge
 // begins. The flags are ONE wave-uniform 64-bit mask (F: lanes that hold an end): the flag half of the scan runs on the scalar
 // unit (a shift, an AND with the row pattern and an OR per step) and a step costs two vector instructions -- the DPP combine and
 // a select on ~F through an SGPR pair. (With per-lane flags a step was five: two DPP moves, compare, select, OR; phase 1 is
-// bound by instruction issue: 526 M vector instructions per SpMV of R-MAT-26 = 0.86 ms of its 0.93, profiles/r03/.)
+// bound by instruction issue: 526 M vector instructions per SpMV of R-MAT-26 = 0.86 ms of its 0.93, profiles/r03/. Later in round 3,
+// with 20 / 40 extra dependent SCALAR instructions per group phase 1 lost 2 % / 11 %, with as many vector ones 1 % / 5.5 %
+// (GT_P1_SBURN / GT_P1_VBURN below, profiles/r03/ab_phase2_flush_and_issue_burn.txt): neither port is saturated any more, and
+// keeping the flags complemented to save the s_not of every step changed nothing.)
 template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry_masked(TV t, uint64_t F) {
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
     TV v = t;
-#ifdef GT_P1_SCAN_NF   // the flags kept COMPLEMENTED (lanes still open): NF' = NF & ((NF << d) | ~pattern) -- shift, or, and per step, no s_not
-    {
-        uint64_t NF = ~F;
-#define GT_NSEG_STEP(CTRL, D, NPAT)                                                \
-        {                                                                          \
-            const TV vs = dpp_get<CTRL, 0xf, TV>(v, neutral);                      \
-            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;         \
-            NF &= (NF << D) | (NPAT);                                              \
-        }
-        GT_NSEG_STEP(0x111, 1, 0x0001000100010001ull)
-        GT_NSEG_STEP(0x112, 2, 0x0003000300030003ull)
-        GT_NSEG_STEP(0x114, 4, 0x000F000F000F000Full)
-        GT_NSEG_STEP(0x118, 8, 0x00FF00FF00FF00FFull)
-#undef GT_NSEG_STEP
-        {   // row_bcast:15 into rows 1, 3: a row stays open for it while the lane that feeds it (15 / 47) is
-            const TV vs = dpp_get<0x142, 0xa, TV>(v, neutral);
-            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;
-            const uint32_t lo = (uint32_t)NF, hi = (uint32_t)(NF >> 32);
-            NF = ((uint64_t)((hi & 0x8000u) ? hi : (hi & 0xFFFFu)) << 32) | ((lo & 0x8000u) ? lo : (lo & 0xFFFFu));
-        }
-        {
-            const TV vs = dpp_get<0x143, 0xc, TV>(v, neutral);
-            v = __builtin_amdgcn_inverse_ballot_w64(NF) ? comb(v, vs) : v;
-        }
-        return dpp_get<0x138, 0xf, TV>(v, neutral);
-    }
-#endif
 #define GT_MSEG_STEP(CTRL, RM, NEXT_F)                                             \
     {                                                                              \
         const TV vs = dpp_get<CTRL, RM, TV>(v, neutral);                           \

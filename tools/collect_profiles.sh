@@ -10,9 +10,9 @@ if [ "$1" == "A" ]; then
   GRAPHTAP_PB_STATS=1 python tools/cold_steps.py > $O/cold_steps_first_process.txt 2>&1
   python bench.py > $O/bench_default.json 2>$O/bench_default.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --no-cpu-baseline --no-f64 > $O/bench_line_under_rocprof.json 2>/dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 3 --warmup 1 > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 3 --warmup 1 > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 3 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
   python3 profiles/collect_pmc.py $O/pmc_fetch $O/pmc_write scale26_gpus1 $O/pmc_traffic.json > /dev/null
   GRAPHTAP_PB_STATS=1 python bench.py --no-cpu-baseline --no-f64 --steps 2 --warmup 1 2>&1 >/dev/null | grep -E "^\[pb\]|^\[build\]" > $O/pb_build_stats_rmat26.txt || true
   GRAPHTAP_PB_PHASE_TIMING=1 python bench.py --no-cpu-baseline > $O/bench_with_phase_times.json 2>/dev/null
