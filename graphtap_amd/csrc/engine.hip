@@ -78,7 +78,7 @@ template <class TX>
 __global__ void k_pack_send(const TX *__restrict__ xseg, const uint32_t *__restrict__ send_idx, uint64_t n, TX *__restrict__ send) {
     // (bound by the line traffic of the gathers, not by their latency: xseg of a tile-row of 8 of R-MAT-26 is 13.5 MB, every XCD's L2 sees
     // all of it, and 12.6 M gathers pull ~1.6 GB of lines out of the Infinity Cache in 73-87 us; four independent chains per thread
-    // were no faster -- rocprofv3, gpurun_out/s3/prof_tr)
+    // were no faster -- rocprofv3, profiles/r03/tilerow3_of_8_kernel_stats.csv; what helped is fewer sweeps: the blocks' tail in column order, ingest.hip)
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) send[i] = xseg[send_idx[i]];
 }
 

@@ -473,6 +473,35 @@ def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, early, known_answers, mo
     P.free(); G.free()
 
 
+@pytest.mark.parametrize("first", [None, "0"])
+def test_cc_first_iteration_is_the_first_neighbour(gt, O, first, known_answers, monkeypatch):
+    """CC on a symmetric graph held by one rank: in iteration 0 every vertex sends its own id (cc.h:33-40), so the min-combiner
+    leaves the smallest neighbour id = the first entry of the vertex's column; the engine reads that instead of sweeping every
+    entry (GRAPHTAP_CC_FIRST=0: the sweep). Labels and iteration counts are the reference's either way, with self-loops kept or
+    dropped; a DIRECTED graph under the CC program always sweeps."""
+    from graphtap_amd.rmat import rmat_edges
+    if first is not None: monkeypatch.setenv("GRAPHTAP_CC_FIRST", first)
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+        r = run_min(gt, "cc", c["edges"], nv)
+        assert (r["label"][:n] == c["np1_cc_a"]).all() and r["iterations"] == known_answers[name]["np1_cc"]["iterations"]
+        if first is None: assert r["stats"].spmspv_iterations >= 1
+    e = rmat_edges(16, 8, 21); nv = 1 << 16
+    for self_loops in (True, False):
+        G = gt.Graph(); G.load_edges(e, nv, nv, False, False, self_loops, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+        og = O.OracleGraph(e, nv, directed=False, transpose=False, self_loops=self_loops, acyclic=False, parallel_edges=False)
+        label, it = og.cc()
+        assert (P.V["label"] == label).all() and P.iteration == it
+        P.free(); G.free()
+    G = gt.Graph(); G.load_edges(e, nv, nv, True, False, True, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    P = gt.CC_Program(G, False, True, False, gt._ROW_); P.execute()
+    og = O.OracleGraph(e, nv, directed=True, transpose=False, self_loops=True, acyclic=False, parallel_edges=False)
+    label, it = og.cc()
+    assert (P.V["label"] == label).all() and P.iteration == it
+    P.free(); G.free()
+
+
 def test_display_lines_match_survey_table(gt):
     """First states printed by the reference on its bundled sample."""
     c = load_case("rmat10")
