@@ -103,6 +103,9 @@ __global__ void k_clear_empty_rows(uint8_t *__restrict__ C, const uint8_t *__res
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < H; v += gridDim.x * blockDim.x)
         if (!(IJ[v] & 1)) C[v] = 0;
 }
+// BFS / SSSP: the root is the only vertex initialize() left active (bfs.h:37-50, sssp.h:33-42), so it is the only one the pass above
+// could change (85 us for the 67 M vertices of R-MAT-26, in iteration 0 of every run)
+__global__ void k_clear_if_empty_row(uint8_t *__restrict__ C, const uint8_t *__restrict__ IJ, uint32_t v) { if (!(IJ[v] & 1)) C[v] = 0; }
 
 __global__ void k_apply_deg_row(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
                                 uint32_t *__restrict__ deg, uint8_t *__restrict__ C) {
@@ -658,6 +661,11 @@ static int init_common(gt_program *p) {
             break;
         default:
             k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
+            {   // the root's place in this rank's segment, if it lives here (one rank: the vertex id itself)
+                const uint64_t ur = (g->perm_mask == 0xFFFFFFFFu) ? p->prm.root : (uint64_t)((p->prm.root * g->perm_a) & g->perm_mask);
+                p->root_here = p->prm.kind != GT_CC && p->prm.root < g->info.nrows && ur >= base && ur < (uint64_t)base + H;
+                p->root_local = p->root_here ? (uint32_t)(ur - base) : 0u;
+            }
             if (p->fl_enabled) {   // the first frontier: the root alone (bfs.h:37-50, sssp.h:33-42), every vertex for CC (cc.h:33-36: no list)
                 GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)g->info.nnzrows / 32 + 1) * 4, s));
                 GT_HIP(hipMemsetAsync(p->d_fl, 0, 4 * sizeof(unsigned int), s));
@@ -699,6 +707,7 @@ static int init_common(gt_program *p) {
     if (g->spmv_variant != GT_SPMV_EDGE && g->pb && p->prm.order == GT_ROW) {   // the value stream of the SpMV this program runs: not inside execute()
         int st = gt_pb_reserve_val(g, p->prm.kind == GT_PR ? 8u : 4u, s);   // PageRank: both message widths (converge mode runs f64 ones)
         if (st != GT_OK) return st;
+        if (!p->stationary) { st = gt_pb_claim_val_min(g, p, p->init_epoch, s); if (st != GT_OK) return st; }   // BFS / SSSP / CC: the neutral fill of the stream, here rather than in the first pass
     }
     { int st = gt_kernels_preload(s); if (st != GT_OK) return st; }
     while (p->ev.size() < 64) { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }   // SpMV timing pairs of the first 32 iterations: not created inside execute()
@@ -1026,7 +1035,10 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
     if (d_active && !fused) GT_HIP(hipMemsetAsync(d_active, 0, sizeof(unsigned long long), s));
     const bool cf = (p->prm.kind == GT_PR && p->prm.compression == GT_TCSC_CF);
     bool list_from_flags = false;
-    if (p->iteration == 0 && !cf) k_clear_empty_rows<<<grid_for(H), TPB, 0, s>>>(p->C, g->IJ, H);
+    if (p->iteration == 0 && !cf) {
+        if (p->prm.kind == GT_BFS || p->prm.kind == GT_SSSP) { if (p->root_here) k_clear_if_empty_row<<<1, 1, 0, s>>>(p->C, g->IJ, p->root_local); }
+        else k_clear_empty_rows<<<grid_for(H), TPB, 0, s>>>(p->C, g->IJ, H);
+    }
     switch (p->prm.kind) {
         case GT_DEG:
             if (p->prm.order == GT_COL) {

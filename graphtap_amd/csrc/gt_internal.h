@@ -200,6 +200,7 @@ struct gt_program {
     uint32_t *bu_long = nullptr;              // [nnzrows] positions in bu_rows of the rows whose first probes found nothing (same allocation)
     uint32_t *bu_first = nullptr;             // [4 nnzrows] the first four entries of every row's column (same allocation, 16-byte aligned; initialize)
     uint64_t bfs_settled = 0;                 // rows reached so far (host estimate from the active counts)
+    bool root_here = false; uint32_t root_local = 0;   // BFS / SSSP: the root's slot in this rank's segment, if it lives here (init_common)
     uint32_t bottom_up_iters = 0;
     // a bottom-up step reads no messages: scatter_gather() defers the messenger when such a step is likely, combine runs it
     // after all if the step is declined, and x is marked stale (the next messenger rewrites all of it) if it was not needed
@@ -265,6 +266,7 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
                const gt_pr_epilogue *epi = nullptr, bool skip_source = false);
 int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s);   // allocates + touches VAL (initialize time)
+int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hipStream_t s);   // initialize() of BFS / SSSP / CC: VAL all infinity(), owned by that program
 uint32_t gt_pb_val_allocs(const gt_graph *g);   // how many times VAL was (re)allocated so far
 uint64_t gt_pb_source_entries(const gt_graph *g);   // entries in chunks of source rows (left out by PageRank/TCSC_CF until the last iteration)
 
