@@ -132,9 +132,6 @@ __global__ void k_block_compact(const uint32_t *__restrict__ send, uint32_t n, c
         if (want) pairs[tab[b].start + slot] = uint2{i - tab[b].start, v};
     }
 }
-__global__ void k_fill_u32(uint32_t *__restrict__ p, uint32_t n, uint32_t v) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
-}
 __global__ void k_scatter_pairs(const uint2 *__restrict__ pairs, uint32_t n, uint32_t *__restrict__ xblock) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint2 pv = pairs[i]; xblock[pv.x] = pv.y; }
 }

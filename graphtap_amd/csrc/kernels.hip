@@ -664,10 +664,18 @@ __global__ void k_cc_first_neighbour(const uint32_t *__restrict__ R2C, const uin
         if (m < y[r]) y[r] = m;
     }
 }
-static int cc_first_iteration_try(gt_program *p, hipStream_t s, bool *done) {
+// (scatter_gather asks too: the step reads no messages, so iteration 0's messenger -- a pass over every slot of x -- is left out;
+// the full apply that follows writes every message anew, combine runs the messenger after all if the step is not taken)
+bool gt_cc_first_likely(const gt_program *p) {
     const gt_graph *g = p->g;
     const char *e = getenv("GRAPHTAP_CC_FIRST");   // 0: iteration 0 sweeps like every other
-    if (p->prm.kind != GT_CC || p->iteration != 0 || g->flags.directed || gt_has_exchange(g) || g->info.nnzrows == 0 || (e && atoi(e) == 0)) return GT_OK;
+    const char *senv = getenv("GRAPHTAP_SPMSPV");  // 0: no sparse path of any kind
+    return p->prm.kind == GT_CC && p->iteration == 0 && !p->converged && !g->flags.directed && !gt_has_exchange(g) && g->info.nnzrows != 0 && g->info.nnz_local != 0 &&
+           !(e && atoi(e) == 0) && !(senv && atoi(senv) == 0);
+}
+static int cc_first_iteration_try(gt_program *p, hipStream_t s, bool *done) {
+    const gt_graph *g = p->g;
+    if (!gt_cc_first_likely(p)) return GT_OK;
     const uint32_t nr = g->info.nnzrows;
     k_cc_first_neighbour<<<(unsigned)std::min<uint64_t>(((uint64_t)nr + TPB - 1) / TPB, 256u * 64u), TPB, 0, s>>>(g->R2C, g->JA, g->IA, g->IR, nr, g->info.rank * g->info.tile_height,
                                                                                                                  (uint32_t *)p->y);
