@@ -212,15 +212,31 @@ template <bool BFS, bool MSG>
 __global__ void __launch_bounds__(TPB) k_apply_rows(const uint32_t *__restrict__ y, const uint32_t *__restrict__ IR, uint32_t nr,
                                                     uint32_t *__restrict__ s0, uint32_t *__restrict__ s1, uint8_t *__restrict__ C, uint32_t iteration,
                                                     unsigned long long *d_active, uint32_t *__restrict__ x, const uint32_t *__restrict__ R2X,
-                                                    uint32_t vid_base, gt_vidmap vm) {
+                                                    uint32_t vid_base, gt_vidmap vm, uint32_t *__restrict__ level_bits = nullptr,
+                                                    uint32_t *__restrict__ reached_bits = nullptr) {
     unsigned act = 0;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nr; r += gridDim.x * blockDim.x) {
-        const uint32_t v = IR[r];
-        const bool c = apply_row<BFS>(v, y[r], s0, s1, iteration);
-        C[v] = c; act += c;
-        if constexpr (MSG) {
-            const uint32_t sl = R2X[r];
-            if (sl != 0xFFFFFFFFu) x[sl] = c ? (BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+    // (whole waves: with the row bitmaps of BFS's bottom-up steps a wave's 64 rows are two words of each -- gt_internal.h, bu_reached)
+    const uint32_t n64 = (nr + 63u) & ~63u;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n64; r += gridDim.x * blockDim.x) {
+        bool c = false;
+        if (r < nr) {
+            const uint32_t v = IR[r];
+            c = apply_row<BFS>(v, y[r], s0, s1, iteration);
+            C[v] = c; act += c;
+            if constexpr (MSG) {
+                const uint32_t sl = R2X[r];
+                if (sl != 0xFFFFFFFFu) x[sl] = c ? (BFS ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v]) : GT_INF;   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+            }
+        }
+        if constexpr (BFS) {
+            if (level_bits) {   // wave-uniform
+                const uint64_t b = __ballot(c);
+                if ((threadIdx.x & 63u) == 0) {
+                    const uint32_t w = r >> 5;
+                    level_bits[w] = (uint32_t)b; level_bits[w + 1] = (uint32_t)(b >> 32);
+                    if (b) { reached_bits[w] |= (uint32_t)b; reached_bits[w + 1] |= (uint32_t)(b >> 32); }
+                }
+            }
         }
     }
     count_active(act, d_active);
@@ -271,14 +287,18 @@ template <bool BFS>
 __global__ void __launch_bounds__(TPB) k_apply_list(const uint32_t *__restrict__ rows, const unsigned int *__restrict__ n_dev, const uint32_t *__restrict__ y,
                                                     const uint32_t *__restrict__ IR, uint32_t *__restrict__ s0, uint32_t *__restrict__ s1,
                                                     uint8_t *__restrict__ C, uint32_t iteration, unsigned long long *d_active,
-                                                    uint32_t *__restrict__ next, unsigned int *__restrict__ next_n, uint32_t cap) {
+                                                    uint32_t *__restrict__ next, unsigned int *__restrict__ next_n, uint32_t cap,
+                                                    uint32_t *__restrict__ level_bits = nullptr, uint32_t *__restrict__ reached_bits = nullptr) {
     unsigned act = 0;
     const uint32_t n = *n_dev, n_round = (n + TPB - 1) / TPB * TPB;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_round; t += gridDim.x * blockDim.x) {
         bool c = false; uint32_t v = 0;
         if (t < n) {
             const uint32_t r = rows[t];
-            if (r != 0xFFFFFFFFu) { v = IR[r]; c = apply_row<BFS>(v, y[r], s0, s1, iteration); C[v] = c; act += c; }   // ~0u: a bottom-up row that found nobody
+            if (r != 0xFFFFFFFFu) {   // ~0u: a bottom-up row that found nobody
+                v = IR[r]; c = apply_row<BFS>(v, y[r], s0, s1, iteration); C[v] = c; act += c;
+                if constexpr (BFS) if (c && level_bits) { atomicOr(&level_bits[r >> 5], 1u << (r & 31u)); atomicOr(&reached_bits[r >> 5], 1u << (r & 31u)); }   // (level_bits zeroed by the caller)
+            }
         }
         if (__syncthreads_or(c)) block_append(c, v, next, next_n, cap);
     }
@@ -597,8 +617,9 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
             if (ok && prm->kind == GT_BFS && !g->flags.directed && !gt_has_exchange(g))   // symmetric graph, whole on one rank: bottom-up steps are possible (kernels.hip)
             {   // + one bit per row, written 4096 rows at a time (k_bu_collect)
                 const uint64_t nrw = std::max<uint32_t>(g->info.nnzrows, 1), bit_words = ((nrw + 4095) / 4096) * 128;
-                ok = hipMalloc((void **)&p->bu_rows, (6 * nrw + bit_words) * 4) == hipSuccess;   // (the quads first: 16-byte aligned)
-                if (ok) { p->bu_first = p->bu_rows; p->bu_rows = p->bu_first + 4 * nrw; p->bu_long = p->bu_rows + nrw; p->bu_bits = p->bu_long + nrw; }
+                ok = hipMalloc((void **)&p->bu_rows, (6 * nrw + 3 * bit_words) * 4) == hipSuccess;   // (the quads first: 16-byte aligned)
+                if (ok) { p->bu_first = p->bu_rows; p->bu_rows = p->bu_first + 4 * nrw; p->bu_long = p->bu_rows + nrw; p->bu_bits = p->bu_long + nrw; p->bu_reached = p->bu_bits + bit_words;
+                          p->bu_next = p->bu_reached + bit_words; p->bu_words = (uint32_t)bit_words; }
                 if (ok && gt_bu_first_neighbours(g, p->bu_first, 0) != GT_OK) ok = false;
             }
         }
@@ -661,11 +682,13 @@ static int init_common(gt_program *p) {
             break;
         default:
             k_init_min<<<grid_for(H), TPB, 0, s>>>(p->prm.kind, H, base, gt_vidmap_of(g), p->prm.root, p->s0, p->s1, p->C);
+            p->bu_maps_valid = false;
             {   // the root's place in this rank's segment, if it lives here (one rank: the vertex id itself)
                 const uint64_t ur = (g->perm_mask == 0xFFFFFFFFu) ? p->prm.root : (uint64_t)((p->prm.root * g->perm_a) & g->perm_mask);
                 p->root_here = p->prm.kind != GT_CC && p->prm.root < g->info.nrows && ur >= base && ur < (uint64_t)base + H;
                 p->root_local = p->root_here ? (uint32_t)(ur - base) : 0u;
             }
+            if (p->prm.kind == GT_BFS && p->bu_first) { int st = gt_bu_maps_init(p, s); if (st != GT_OK) return st; }
             if (p->fl_enabled) {   // the first frontier: the root alone (bfs.h:37-50, sssp.h:33-42), every vertex for CC (cc.h:33-36: no list)
                 GT_HIP(hipMemsetAsync(p->row_mark, 0, ((uint64_t)g->info.nnzrows / 32 + 1) * 4, s));
                 GT_HIP(hipMemsetAsync(p->d_fl, 0, 4 * sizeof(unsigned int), s));
@@ -1076,7 +1099,10 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
                 if (!p->fl_cur_valid) GT_HIP(hipMemsetAsync(p->C, 0, H, s));
                 else if (p->fl_cur_n) k_list_clear_flags<<<gl, TPB, 0, s>>>(p->C, p->fl_v[p->fl_cur], p->d_fl + p->fl_cur);
                 const unsigned ga = 1024;   // the length is on the device; the rounds are uniform per workgroup
-                if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap);
+                const bool maps = bfs && p->bu_maps_valid && !p->bu_step_emitted;   // (a bottom-up step wrote the next level itself)
+                if (maps) GT_HIP(hipMemsetAsync(p->bu_bits, 0, (size_t)p->bu_words * 4, s));   // the rows this apply reaches = the next level
+                if (bfs) k_apply_list<true><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap,
+                                                               maps ? p->bu_bits : nullptr, maps ? p->bu_reached : nullptr);
                 else k_apply_list<false><<<ga, TPB, 0, s>>>(p->fl_rows, p->d_fl + 2, (const uint32_t *)p->y, g->IR, p->s0, p->s1, p->C, p->iteration, d_active, next, next_n, p->fl_cap);
                 p->list_iters++;
             } else {
@@ -1093,7 +1119,9 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
                     p->rowless_reset = true;
                 }
                 if (nr && bfs && msg) k_apply_rows<true, true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, xm, gt_row_slot(g), vb, gt_vidmap_of(g));
-                else if (nr && bfs) k_apply_rows<true, false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, nullptr, nullptr, 0, gt_vidmap_of(g));
+                else if (nr && bfs) k_apply_rows<true, false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, nullptr, nullptr, 0, gt_vidmap_of(g),
+                                                                                          (p->bu_maps_valid && !p->bu_step_emitted) ? p->bu_bits : nullptr,
+                                                                                          (p->bu_maps_valid && !p->bu_step_emitted) ? p->bu_reached : nullptr);
                 else if (nr && msg) k_apply_rows<false, true><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, xm, gt_row_slot(g), vb, gt_vidmap_of(g));
                 else if (nr) k_apply_rows<false, false><<<grid_for(nr), TPB, 0, s>>>((const uint32_t *)p->y, g->IR, nr, p->s0, p->s1, p->C, p->iteration, d_active, nullptr, nullptr, 0, gt_vidmap_of(g));
                 if (msg) { p->x_fresh = true; p->x_stale = false; }
@@ -1106,6 +1134,7 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
         }
     }
     GT_HIP(hipGetLastError());
+    p->bu_step_emitted = false;
     p->iteration++;  // vp:421
     *list_from_flags_out = list_from_flags && !deferred;
     return GT_OK;
@@ -1208,6 +1237,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
             if (!p->stationary && !phase_timing) {   // a short list: the rest of the run -- or as much of it as stays short -- in one launch
                 bool conv = false; uint32_t ran = 0;
                 st = gt_tail_try(p, s, &conv, &ran); if (st != GT_OK) return st;
+                if (ran) p->bu_maps_valid = false;   // iterations that ran inside the tail kernel did not keep the row bitmaps
                 if (conv) { st = gt_program_finish_converged(p); if (st != GT_OK) return st; break; }
             }
         } else if (p->iteration >= iters) break;

@@ -433,6 +433,114 @@ __global__ void __launch_bounds__(TPB) k_bu_first_rest(const uint32_t *__restric
     }
 }
 
+// ---- the same step WITHOUT the collecting pass: BFS's apply kernels keep two row bitmaps (gt_internal.h, bu_reached): one pass over
+// the rows, 2048 at a time -- a reached row costs its bit; an unreached one probes as above. The rows that found a parent are
+// appended to `rows_out` (one reservation per 2048 rows; null: the full apply follows), the long ones to `long_list`.
+__global__ void __launch_bounds__(TPB) k_bu_probe_all(uint32_t *reached_bits, const uint32_t *__restrict__ level_bits, uint32_t *__restrict__ next_bits,
+                                                      const BuQuad *__restrict__ FN, const uint32_t *__restrict__ IR, uint32_t nr, uint32_t vid_base,
+                                                      uint32_t *__restrict__ y, uint32_t *__restrict__ rows_out, unsigned int *__restrict__ rows_n,
+                                                      uint32_t *__restrict__ long_list, unsigned int *__restrict__ long_n) {
+    // The rows that find a parent ARE the next level (BFS's apply accepts every one of them): a wave writes the two words of its 64
+    // rows into `next_bits` and ORs them into `reached_bits` (its own words: nobody else touches them), so the apply that follows
+    // leaves the bitmaps alone (3.7 M atomic ORs cost the row-list apply of R-MAT-26's iteration 2 0.1 ms).
+    constexpr uint32_t PER = 8, SPAN = PER * TPB;
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned span_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t nspan = (nr + SPAN - 1) / SPAN;
+    auto reserve = [&](uint32_t cnt, unsigned int *cursor) -> uint32_t {   // exclusive position of this thread's first item; all threads call
+        uint32_t inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= (uint32_t)o) inc += t; }
+        if (lane == 63) wave_n[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+            for (int w = 0; w < TPB / 64; w++) { const unsigned c = wave_n[w]; wave_n[w] = total; total += c; }
+            span_base = total ? atomicAdd(cursor, total) : 0u;
+        }
+        __syncthreads();
+        const uint32_t o = span_base + wave_n[wave] + inc - cnt;
+        __syncthreads();
+        return o;
+    };
+    for (uint32_t sp = blockIdx.x; sp < nspan; sp += gridDim.x) {
+        uint32_t mfound = 0, nfound = 0, mlong = 0, nlong = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t r = sp * SPAN + k * TPB + threadIdx.x;
+            bool found = false;
+            if (r < nr && !bu_on_level(reached_bits, r)) {
+                const BuQuad q = FN[r];
+                uint32_t hitnb = 0xFFFFFFFFu;
+                if (q.v[0] != 0xFFFFFFFFu) {
+                    const bool h0 = bu_on_level(level_bits, q.v[0]), h1 = q.v[1] != 0xFFFFFFFFu && bu_on_level(level_bits, q.v[1]);
+                    hitnb = h0 ? q.v[0] : h1 ? q.v[1] : 0xFFFFFFFFu;
+                    if (hitnb == 0xFFFFFFFFu && q.v[2] != 0xFFFFFFFFu) {
+                        const bool h2 = bu_on_level(level_bits, q.v[2]), h3 = q.v[3] != 0xFFFFFFFFu && bu_on_level(level_bits, q.v[3]);
+                        hitnb = h2 ? q.v[2] : h3 ? q.v[3] : 0xFFFFFFFFu;
+                    }
+                }
+                if (hitnb != 0xFFFFFFFFu) { const uint32_t cand = vid_base + IR[hitnb]; if (cand < y[r]) y[r] = cand; found = true; mfound |= 1u << k; nfound++; }
+                else if (q.v[3] != 0xFFFFFFFFu) { mlong |= 1u << k; nlong++; }   // four entries and no hit: there may be more
+            }
+            const uint64_t b = __ballot(found);   // rows r - lane .. r - lane + 63
+            if (lane == 0) {
+                const uint32_t w = (sp * SPAN + k * TPB + wave * 64) >> 5;
+                next_bits[w] = (uint32_t)b; next_bits[w + 1] = (uint32_t)(b >> 32);
+                if (b) { reached_bits[w] |= (uint32_t)b; reached_bits[w + 1] |= (uint32_t)(b >> 32); }
+            }
+        }
+        if (rows_out) {
+            uint32_t o = reserve(nfound, rows_n);
+            for (uint32_t k = 0; mfound; k++, mfound >>= 1) if (mfound & 1u) rows_out[o++] = sp * SPAN + k * TPB + threadIdx.x;
+        }
+        uint32_t o = reserve(nlong, long_n);
+        for (uint32_t k = 0; mlong; k++, mlong >>= 1) if (mlong & 1u) long_list[o++] = sp * SPAN + k * TPB + threadIdx.x;
+    }
+}
+template <uint32_t LPR>
+__global__ void __launch_bounds__(TPB) k_bu_rest_rows(const uint32_t *__restrict__ long_list, const unsigned int *__restrict__ long_n, const uint32_t *__restrict__ R2C,
+                                                      const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA, const uint32_t *__restrict__ IR,
+                                                      const uint32_t *__restrict__ level_bits, uint32_t vid_base, uint32_t *__restrict__ y,
+                                                      uint32_t *__restrict__ rows_out, unsigned int *__restrict__ rows_n, uint32_t *__restrict__ next_bits,
+                                                      uint32_t *__restrict__ reached_bits) {
+    constexpr uint32_t GPB = TPB / LPR;
+    const uint32_t n = *long_n, sub = threadIdx.x & (LPR - 1), gbase = (threadIdx.x & 63u) & ~(LPR - 1);
+    for (uint32_t li = blockIdx.x * GPB + threadIdx.x / LPR; li < n; li += gridDim.x * GPB) {
+        uint32_t cand = GT_INF;
+        const uint32_t r = long_list[li], c = R2C[r];
+        for (uint32_t base = JA[c] + BU_PROBE, e1 = JA[c + 1]; base < e1; base += LPR) {
+            const uint32_t e = base + sub;
+            uint32_t nb = 0; bool hit = false;
+            if (e < e1) { nb = IA[e]; hit = bu_on_level(level_bits, nb); }
+            const uint32_t m = (uint32_t)(__ballot(hit) >> gbase) & (LPR == 32 ? 0xFFFFFFFFu : ((1u << LPR) - 1u));
+            if (m) { cand = vid_base + IR[__shfl(nb, (int)(gbase + (uint32_t)__ffs((int)m) - 1u))]; break; }
+        }
+        if (sub == 0 && cand != GT_INF) {
+            if (cand < y[r]) y[r] = cand;
+            if (rows_out) rows_out[atomicAdd(rows_n, 1u)] = r;   // (few rows come this far)
+            atomicOr(&next_bits[r >> 5], 1u << (r & 31u)); atomicOr(&reached_bits[r >> 5], 1u << (r & 31u));
+        }
+    }
+}
+__global__ void k_bu_maps_root(const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ IV, uint32_t v, uint32_t *__restrict__ level_bits, uint32_t *__restrict__ reached_bits) {
+    if (IJ[v] & 1u) { const uint32_t r = IV[v]; level_bits[r >> 5] = 1u << (r & 31u); reached_bits[r >> 5] = 1u << (r & 31u); }
+}
+// entries of the columns of a frontier list's vertices (how heavy the frontier is)
+__global__ void k_list_entries(const uint32_t *__restrict__ list, uint32_t n, const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ JA,
+                               unsigned long long *__restrict__ out) {
+    unsigned long long e = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = list[i];
+        if (IJ[v] & 2u) { const uint32_t c = JV[v]; e += JA[c + 1] - JA[c]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    __shared__ unsigned long long ws[TPB / 64];
+    if ((threadIdx.x & 63u) == 0) ws[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < TPB / 64; w++) e += ws[w]; if (e) atomicAdd(out, e); }
+}
+
 // ---- frontier lists (vertices changed by the last apply)
 __device__ __forceinline__ uint32_t slot_of_vertex(const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ xslot, uint32_t v) {
     if (!(IJ[v] & 2u)) return 0xFFFFFFFFu;   // no column: the vertex sends nothing
@@ -713,6 +821,64 @@ bool gt_bfs_bottom_up_likely(const gt_program *p) {
     return unreached < p->last_active || (p->last_active > 65536 && p->last_active * 64 >= nr);
 }
 
+int gt_bu_maps_init(gt_program *p, hipStream_t s) {
+    const gt_graph *g = p->g;
+    const char *e = getenv("GRAPHTAP_BFS_BU_MAPS");   // 0: every bottom-up step collects the unreached rows and the level from the vertex states
+    p->bu_maps_valid = false;
+    if (!p->bu_first || !p->bu_reached || !p->bu_next || (e && atoi(e) == 0)) return GT_OK;
+    for (uint32_t *m : {p->bu_bits, p->bu_next, p->bu_reached}) GT_HIP(hipMemsetAsync(m, 0, (size_t)p->bu_words * 4, s));
+    p->bu_step_emitted = false;
+    if (p->root_here) k_bu_maps_root<<<1, 1, 0, s>>>(g->IJ, g->IV, p->root_local, p->bu_bits, p->bu_reached);
+    GT_HIP(hipGetLastError());
+    p->bu_maps_valid = true;
+    return GT_OK;
+}
+
+// the bottom-up step from the row bitmaps (no collecting pass). The decision uses the host's counts: rows still unreached
+// (nnzrows - vertices reached so far) and, for a frontier that is a list, the entries of its columns.
+static int bfs_bottom_up_maps_try(gt_program *p, hipStream_t s, bool *done) {
+    const gt_graph *g = p->g;
+    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const int mode = menv ? atoi(menv) : -1;
+    const bool dbg = getenv("GRAPHTAP_PB_STATS") != nullptr;
+    const uint64_t nr = g->info.nnzrows, nnz = g->info.nnz_local;
+    const uint64_t unreached = nr > p->bfs_settled ? nr - p->bfs_settled : 0;
+    constexpr uint32_t LPR = 16;
+    bool take = mode == 1 || (p->last_active != ~0ull && unreached < p->last_active);   // few rows left: the classic switch
+    uint64_t fe = 0;
+    if (!take) {   // a heavy frontier: a row's first probes are likely to hit
+        if (p->fl_cur_valid && p->fl_cur_n) {
+            GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
+            k_list_entries<<<(unsigned)std::min<uint64_t>(((uint64_t)p->fl_cur_n + TPB - 1) / TPB, 4096), TPB, 0, s>>>(p->fl_v[p->fl_cur], p->fl_cur_n, g->IJ, g->JV, g->JA, p->d_frontier + 1);
+            unsigned long long h = 0;
+            GT_HIP(hipMemcpyAsync(&h, p->d_frontier + 1, sizeof(h), hipMemcpyDeviceToHost, s));
+            GT_HIP(hipStreamSynchronize(s));
+            fe = h;
+        } else if (p->last_active != ~0ull && p->last_active * 8 >= nr) fe = nnz / 2;   // not even a list: most of the graph is on the level
+        const uint64_t per_row = fe ? std::max<uint64_t>(LPR, nnz / fe) : ~0ull;
+        take = fe != 0 && per_row < nnz && unreached * per_row * 2 <= nnz;
+    }
+    if (dbg) fprintf(stderr, "[bfs] iteration %u: %llu rows unreached, %llu vertices active, the frontier's columns hold %llu entries: %s\n", p->iteration,
+                     (unsigned long long)unreached, (unsigned long long)p->last_active, (unsigned long long)fe, take ? "bottom-up step (row bitmaps)" : "push sweep");
+    if (!take) return GT_OK;
+    const bool rows_list = unreached * 8 <= nr;   // else the full apply (the row-list apply of 31.8 M rows took 1.5 ms, the full one 0.27)
+    GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
+    GT_HIP(hipMemsetAsync(p->d_frontier + 3, 0, sizeof(unsigned long long), s));
+    unsigned int *long_n = (unsigned int *)(p->d_frontier + 3);
+    uint32_t *rows_out = rows_list ? p->fl_rows : nullptr;
+    const uint32_t vb = g->info.rank * g->info.tile_height;
+    k_bu_probe_all<<<(unsigned)std::min<uint64_t>((nr + 2047) / 2048, 256u * 64u), TPB, 0, s>>>(p->bu_reached, p->bu_bits, p->bu_next, reinterpret_cast<const BuQuad *>(p->bu_first), g->IR,
+                                                                                                (uint32_t)nr, vb, (uint32_t *)p->y, rows_out, p->d_fl + 2, p->bu_long, long_n);
+    k_bu_rest_rows<LPR><<<4096, TPB, 0, s>>>(p->bu_long, long_n, g->R2C, g->JA, g->IA, g->IR, p->bu_bits, vb, (uint32_t *)p->y, rows_out, p->d_fl + 2, p->bu_next, p->bu_reached);
+    GT_HIP(hipGetLastError());
+    std::swap(p->bu_bits, p->bu_next);   // the rows that found a parent are the next level; the apply of this iteration leaves the bitmaps alone
+    p->bu_step_emitted = true;
+    p->bottom_up_iters++; p->spmspv_iters++;
+    p->fl_rows_valid = rows_list;
+    *done = true;
+    return GT_OK;
+}
+
 static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
     const gt_graph *g = p->g;
     const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
@@ -721,6 +887,7 @@ static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
     const bool early = !(eenv && atoi(eenv) == 0);
     const bool dbg = getenv("GRAPHTAP_PB_STATS") != nullptr;
     if (!gt_bfs_bottom_up_likely(p)) return GT_OK;
+    if (p->bu_maps_valid && early) return bfs_bottom_up_maps_try(p, s, done);
     const uint32_t nr = g->info.nnzrows;
     if (dbg) fprintf(stderr, "[bfs] iteration %u: %llu rows unreached (estimate), %llu vertices active\n", p->iteration,
                      (unsigned long long)(nr > p->bfs_settled ? nr - p->bfs_settled : 0), (unsigned long long)p->last_active);

@@ -440,7 +440,7 @@ def test_frontier_lists_are_bit_exact(gt, O, lists, spmspv, known_answers, monke
     if lists == "1": assert got["stats"].list_iterations > 0   # the tail iterations of CC
 
 
-@pytest.mark.parametrize("early", [None, "0"])
+@pytest.mark.parametrize("early", [None, "0", "collect"])
 @pytest.mark.parametrize("mode", ["1", "0", None])
 def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, early, known_answers, monkeypatch):
     """BFS on a symmetric graph (apps/bfs.cpp loads with directed = false) may run an iteration bottom-up: the unreached rows
@@ -451,8 +451,11 @@ def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, early, known_answers, mo
     the step run against a large frontier; GRAPHTAP_BFS_BU_EARLY=0 is the form that looks at every neighbour."""
     from graphtap_amd.rmat import rmat_edges
     if mode is not None: monkeypatch.setenv("GRAPHTAP_BFS_BOTTOM_UP", mode)
-    if early is not None: monkeypatch.setenv("GRAPHTAP_BFS_BU_EARLY", early)
-    if early == "0" and mode == "0": pytest.skip("no bottom-up step at all: covered by the default form")
+    # default: the step works from the row bitmaps BFS's apply kernels keep (reached / current level); "collect": a pass over the vertex
+    # states collects the unreached rows and the level for every step (GRAPHTAP_BFS_BU_MAPS=0); "0": that pass + every neighbour looked at
+    if early == "0": monkeypatch.setenv("GRAPHTAP_BFS_BU_EARLY", "0")
+    if early == "collect": monkeypatch.setenv("GRAPHTAP_BFS_BU_MAPS", "0")
+    if early is not None and mode == "0": pytest.skip("no bottom-up step at all: covered by the default form")
     for name in CASES:
         c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
         for root, tag in ((c["root"], ""), (0, "0")) if c["root"] != 0 else ((0, ""),):
