@@ -858,7 +858,7 @@ int gt_program_scatter_gather(gt_program *p) {
             break;
         }
         default:
-            p->x_deferred = gt_bfs_bottom_up_likely(p) || gt_cc_first_likely(p);   // the step needs no messages: combine writes them if it is declined
+            p->x_deferred = gt_bfs_bottom_up_likely(p) || gt_cc_first_likely(p) || gt_list_spmspv_likely(p);   // the step needs no messages: combine writes them if it is declined
             if (!p->x_deferred) { int st = gt_min_messenger(p); if (st != GT_OK) return st; }
             break;
     }

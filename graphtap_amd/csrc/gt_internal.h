@@ -320,6 +320,7 @@ int gt_bu_first_neighbours(const gt_graph *g, uint32_t *FN, hipStream_t s);   //
 int gt_bu_maps_init(gt_program *p, hipStream_t s);   // BFS initialize(): both row bitmaps = the root's row
 bool gt_frontier_list_worth(const gt_program *p, uint64_t n);   // kernels.hip
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
+bool gt_list_spmspv_likely(const gt_program *p);   // the frontier is a short list and the messenger would be a full pass (kernels.hip)
 bool gt_cc_first_likely(const gt_program *p);        // CC's iteration 0 will read first entries instead of sweeping (kernels.hip)
 extern "C" int gt_min_messenger(gt_program *p);      // the messenger of BFS / SSSP / CC, now (engine.hip, inside its extern "C" block; not part of the ABI header)   // loads the code object of kernels.hip (called by initialize)
 int gt_spmspv_reserve(gt_program *p, uint32_t nact);
