@@ -1009,9 +1009,46 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
 }
 
 // The same from the frontier LIST (gt_internal.h): no pass over x; the rows it lowers are left in fl_rows for apply().
+// A frontier of ONE vertex (iteration 0 of BFS / SSSP: the root, whose column holds a million entries on R-MAT-26): its column's entries
+// straight into y, the rows it lowers straight into the row list -- one launch instead of the eight of the general path (list ->
+// frontier arrays, short / long split, scan, two kernels, bitmap -> rows: 0.16 ms).
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(TPB) k_spmspv_one(const uint32_t *__restrict__ list, const uint8_t *__restrict__ IJ, const uint32_t *__restrict__ JV, const uint32_t *__restrict__ JA,
+                                                    const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A, const uint32_t *__restrict__ s0, uint32_t vid_base, gt_vidmap vm,
+                                                    int kind, uint32_t *__restrict__ y, uint32_t *__restrict__ rows_out, unsigned int *__restrict__ rows_n) {
+    __shared__ unsigned wave_n[TPB / 64];
+    __shared__ unsigned base;
+    const uint32_t v = list[0];
+    if (!(IJ[v] & 2u)) return;   // no column: the vertex sends nothing
+    const uint32_t c = JV[v], e0 = JA[c], e1 = JA[c + 1];
+    const uint32_t m = (kind == GT_BFS) ? gt_vid_of(vm, (uint64_t)vid_base + v) : s0[v];   // bfs.h:52-54, sssp.h:44-46, cc.h:38-40
+    if (m == GT_INF) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n = e1 - e0, n_round = (n + TPB - 1) / TPB * TPB;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_round; i += gridDim.x * TPB) {
+        bool low = false; uint32_t r = 0;
+        if (i < n) { r = IA[e0 + i]; const uint32_t val = WEIGHTED ? m + A[e0 + i] : m; low = val < atomicMin(&y[r], val); }
+        const uint64_t b = __ballot(low);
+        if (lane == 0) wave_n[wave] = (unsigned)__popcll((unsigned long long)b);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned t = 0; for (int w = 0; w < TPB / 64; w++) { const unsigned k = wave_n[w]; wave_n[w] = t; t += k; } base = t ? atomicAdd(rows_n, t) : 0u; }
+        __syncthreads();
+        if (low) rows_out[base + wave_n[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = r;
+        __syncthreads();
+    }
+}
+
 static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done) {
     const gt_graph *g = p->g;
     const uint32_t nact = p->fl_cur_n;
+    if (nact == 1 && !(getenv("GRAPHTAP_SPMSPV_ONE") && atoi(getenv("GRAPHTAP_SPMSPV_ONE")) == 0)) {
+        GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s));
+        const uint32_t vb = g->info.rank * g->info.tile_height;
+        if (p->semiring == GT_MINPLUS_U32) k_spmspv_one<true><<<1024, TPB, 0, s>>>(p->fl_v[p->fl_cur], g->IJ, g->JV, g->JA, g->IA, g->A, p->s0, vb, gt_vidmap_of(g), p->prm.kind, (uint32_t *)p->y, p->fl_rows, p->d_fl + 2);
+        else k_spmspv_one<false><<<1024, TPB, 0, s>>>(p->fl_v[p->fl_cur], g->IJ, g->JV, g->JA, g->IA, nullptr, p->s0, vb, gt_vidmap_of(g), p->prm.kind, (uint32_t *)p->y, p->fl_rows, p->d_fl + 2);
+        GT_HIP(hipGetLastError());
+        p->spmspv_iters++; p->fl_rows_valid = true; *done = true;
+        return GT_OK;
+    }
     if (nact == 0) { *done = true; p->fl_rows_valid = true; GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s)); return GT_OK; }   // nothing is active: y keeps its minima
     if (!force) {   // counting costs a pass over the list and a round trip (0.15 ms at 8 M vertices): not for a frontier that cannot
                     // qualify -- the mid-run frontiers hold 8+ entries per vertex, only the tail ones fewer (1.3)
