@@ -563,6 +563,7 @@ int gt_program_free(gt_program *p) {
     void *ptrs[] = {p->d_tail, p->bu_first, p->fl_v[0], p->fl_v[1], p->fl_rows, p->row_mark, p->d_fl, p->s0, p->s1, p->rank, p->C, p->x_own, p->y, p->d_active, p->rank_c, p->deg_c, p->C_c, p->xseg, p->send_own,
                     p->fr_col, p->fr_val, p->fr_off, p->fr_tmp, p->d_frontier};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (p->h_pinned) (void)hipHostFree(p->h_pinned);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slice_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slice_done) (void)hipEventDestroy(e);
@@ -601,7 +602,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
     bool ok = hipMalloc((void **)&p->s0, (uint64_t)H * 4) == hipSuccess && hipMalloc((void **)&p->C, H) == hipSuccess &&
               hipMalloc(&p->x_own, std::max<uint64_t>(p->x_elems, 1) * p->x_alloc_bytes) == hipSuccess &&
               hipMalloc(&p->y, std::max<uint64_t>(p->y_elems, 1) * p->y_bytes) == hipSuccess &&
-              hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc((void **)&p->d_active, sizeof(unsigned long long)) == hipSuccess && hipHostMalloc(&p->h_pinned, 256, hipHostMallocDefault) == hipSuccess;
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
     {   // frontier lists of the min programs: the vertices the last apply changed (on several ranks: the rank's own, local ids;
         // the C++ driver turns them into (index, value) pairs for the peers and runs the SpMSpV from the pairs it receives, dist.hip)
@@ -1160,6 +1161,23 @@ static int apply_finish(gt_program *p, bool counted, unsigned long long h, bool 
     return GT_OK;
 }
 
+int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hipStream_t s) {
+    static const bool plain = getenv("GRAPHTAP_PLAIN_READBACK") != nullptr;   // A/B: pageable copy + hipStreamSynchronize
+    if (plain || !p->h_pinned || bytes > 256) {
+        GT_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        GT_HIP(hipStreamSynchronize(s));
+        return GT_OK;
+    }
+    GT_HIP(hipMemcpyAsync(p->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { gt_set_error("stream failed while reading back %zu bytes: %s", bytes, hipGetErrorString(e)); return GT_ERR_HIP; }
+    }
+    memcpy(dst, p->h_pinned, bytes);
+    return GT_OK;
+}
+
 int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "apply before initialize");
     // converged: apply_*() is skipped (vp:1616-1632) but the driver still counts the trip (vp:421), so a later
@@ -1170,8 +1188,7 @@ int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
     if (st != GT_OK) return st;
     unsigned long long h = 0;
     if (active) {
-        GT_HIP(hipMemcpyAsync(&h, p->d_active, sizeof(h), hipMemcpyDeviceToHost, p->stream));
-        GT_HIP(hipStreamSynchronize(p->stream));
+        st = gt_read_back(p, &h, p->d_active, sizeof(h), p->stream); if (st != GT_OK) return st;
         *active = h;
     }
     return apply_finish(p, active != nullptr, h, lff);

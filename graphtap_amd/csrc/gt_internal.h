@@ -148,6 +148,7 @@ struct gt_program {
     uint64_t x_elems = 0, y_elems = 0;
     uint32_t x_bytes = 4, y_bytes = 4;
     unsigned long long *d_active = nullptr;
+    void *h_pinned = nullptr;   // 256 pinned host bytes: the few words an iteration reads back (gt_read_back)
     // PageRank working set in compressed-row space (dense, sequential): the V-space arrays above are
     // brought up to date lazily (pr_sync_state) when somebody looks at V
     double *rank_c = nullptr;   // [nnzrows]
@@ -318,6 +319,9 @@ int gt_frontier_messages(gt_program *p, hipStream_t s);
 int gt_kernels_preload(hipStream_t s);
 int gt_bu_first_neighbours(const gt_graph *g, uint32_t *FN, hipStream_t s);   // fills gt_program::bu_first
 int gt_bu_maps_init(gt_program *p, hipStream_t s);   // BFS initialize(): both row bitmaps = the root's row
+// A few words from the device, once per iteration (the active count, a frontier's entry count): through the program's pinned
+// buffer and a spin on the stream instead of a pageable copy + hipStreamSynchronize (engine.hip)
+extern "C" int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hipStream_t s);   // (inside engine.hip's extern "C" block; not part of the ABI header)
 bool gt_frontier_list_worth(const gt_program *p, uint64_t n);   // kernels.hip
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
 bool gt_list_spmspv_likely(const gt_program *p);   // the frontier is a short list and the messenger would be a full pass (kernels.hip)

@@ -710,8 +710,7 @@ int gt_tail_try(gt_program *p, hipStream_t s, bool *converged, uint32_t *iterati
 #undef GT_TAIL_LAUNCH
     GT_HIP(hipGetLastError());
     TailOut h{};
-    GT_HIP(hipMemcpyAsync(&h, out, sizeof(h), hipMemcpyDeviceToHost, s));
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_read_back(p, &h, out, sizeof(h), s); if (st != GT_OK) return st; }
     if (h.iterations == 0) return GT_OK;   // too many entries in the very first list: nothing was touched
     p->iteration += h.iterations;
     p->spmspv_iters += h.iterations; p->list_iters += h.iterations; p->tail_iters += h.iterations;
@@ -860,8 +859,7 @@ static int bfs_bottom_up_maps_try(gt_program *p, hipStream_t s, bool *done) {
             GT_HIP(hipMemsetAsync(p->d_frontier, 0, 4 * sizeof(unsigned long long), s));
             k_list_entries<<<(unsigned)std::min<uint64_t>(((uint64_t)p->fl_cur_n + TPB - 1) / TPB, 4096), TPB, 0, s>>>(p->fl_v[p->fl_cur], p->fl_cur_n, g->IJ, g->JV, g->JA, p->d_frontier + 1);
             unsigned long long h = 0;
-            GT_HIP(hipMemcpyAsync(&h, p->d_frontier + 1, sizeof(h), hipMemcpyDeviceToHost, s));
-            GT_HIP(hipStreamSynchronize(s));
+            { int st = gt_read_back(p, &h, p->d_frontier + 1, sizeof(h), s); if (st != GT_OK) return st; }
             fe = h;
         } else if (p->last_active != ~0ull && p->last_active * 8 >= nr) fe = nnz / 2;   // not even a list: most of the graph is on the level
         const uint64_t per_row = fe ? std::max<uint64_t>(LPR, nnz / fe) : ~0ull;
@@ -1071,8 +1069,7 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
         return GT_OK;
     }
     unsigned long long h[2] = {0, 0};
-    GT_HIP(hipMemcpyAsync(h, p->d_frontier, sizeof(h), hipMemcpyDeviceToHost, s));
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_read_back(p, h, p->d_frontier, sizeof(h), s); if (st != GT_OK) return st; }
     if (h[1] == 0) { *done = true; p->fl_rows_valid = true; return GT_OK; }
     // From the list, with eight lanes per column, the sparse pass wins up to ~nnz/32 entries (tools/spmspv_sweep.sh on R-MAT-26:
     // 10 M entries of 1.27 M columns 0.41 against 1.49 ms, 4.7 M of 3.7 M columns 0.41 against 0.95 ms, but 102 M entries of
