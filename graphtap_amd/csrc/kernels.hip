@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(TPB) k_bu_probe_all(uint32_t *reached_bits, co
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t r = sp * SPAN + k * TPB + threadIdx.x;
             bool found = false;
-            if (r < nr && !bu_on_level(reached_bits, r)) {
+            if (r < nr && !((reached_bits[r >> 5] >> (r & 31u)) & 1u)) {   // (read in place: this wave rewrites the word below)
                 const BuQuad q = FN[r];
                 uint32_t hitnb = 0xFFFFFFFFu;
                 if (q.v[0] != 0xFFFFFFFFu) {
