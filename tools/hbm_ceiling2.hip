@@ -169,6 +169,10 @@ int main(int argc, char **argv) {
         timeit("mix 3 reads : 2 writes nt loads", g, per3 * g * 16.0 * (1 + 2.0 / 3) / 1e9, [&] { k_mix<3, 2, true><<<g, 256>>>(a, b, n); });
         timeit("mix 7 reads : 1 write  plain", g, per7 * g * 16.0 * (1 + 1.0 / 7) / 1e9, [&] { k_mix<7, 1, false><<<g, 256>>>(a, b, n); });
         timeit("mix 7 reads : 1 write  nt loads", g, per7 * g * 16.0 * (1 + 1.0 / 7) / 1e9, [&] { k_mix<7, 1, true><<<g, 256>>>(a, b, n); });
+        // phase 2 with the lean applicator writes one byte in seventeen; how fast does the mix approach the pure-read rate?
+        const uint64_t per16 = (n / g / (256 * 16)) * (256 * 16), per32 = (n / g / (256 * 32)) * (256 * 32);
+        timeit("mix 16 reads : 1 write nt loads", g, per16 * g * 16.0 * (1 + 1.0 / 16) / 1e9, [&] { k_mix<16, 1, true><<<g, 256>>>(a, b, n); });
+        timeit("mix 32 reads : 1 write nt loads", g, per32 * g * 16.0 * (1 + 1.0 / 32) / 1e9, [&] { k_mix<32, 1, true><<<g, 256>>>(a, b, n); });
     }
     // hipMemcpy D2D as the runtime's own copy
     timeit("hipMemcpyAsync D2D (r+w bytes)", 0, 2 * G, [&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); });
