@@ -949,7 +949,9 @@ int gt_layout_build(gt_graph *g) {
     // instead of 24 is 393 M instead of 400 M slots on R-MAT-26 and ~3 % (PageRank 1.59 -> 1.54 ms, A/B); the weighted graphs
     // (SSSP: direct stores) keep 24, where 12 was 3-4 % slower; BFS / CC are indifferent.
     const char *et = getenv("GRAPHTAP_PB_HUB_DEG");
-    const uint32_t thr = et ? (uint32_t)atoi(et) : (g->info.weighted ? 24u : 12u);
+    // Re-measured with round 3's final kernels (profiles/r03/ab_hub_threshold_final.txt, four rounds on one box): 8 or 10 instead of 12 is a
+    // steady 1 % for PageRank (phase 2 -2 %: fewer slots), nothing for BFS and +1-2 % for CC on their symmetrised graphs: 8 on directed graphs.
+    const uint32_t thr = et ? (uint32_t)atoi(et) : (g->info.weighted ? 24u : g->flags.directed ? 8u : 12u);
     struct Buf { void *p = nullptr; ~Buf() { if (p) gt_scratch_free(p); } } deg, hubflag, tailflag, hubpos, tailpos, key, key2, col, col2, tmp;
     for (Buf *b : {&deg, &hubflag, &tailflag, &hubpos, &tailpos}) LAY_HIP(gt_scratch_malloc(&b->p, (uint64_t)(nc + 1) * 4));
     LAY_HIP(hipMemsetAsync(hubflag.p, 0, (uint64_t)(nc + 1) * 4, s));
