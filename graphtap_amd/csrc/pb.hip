@@ -666,8 +666,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
-    __syncthreads();
+    // The first trip's loads go out BEFORE the window is staged for the plus semirings (-0.5 to -1 % of phase 1, A/B of three rounds,
+    // profiles/r03/ab_prefetch_before_staging.txt); the min programs stage first: a chunk their activity filter skips should not have
+    // fetched 48 KiB of its entry stream
+    constexpr bool PREFETCH = !IS_MIN;
+    if constexpr (!PREFETCH) {
+        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
+        __syncthreads();
+    }
     constexpr uint32_t NW = P1_THREADS / 64;
     constexpr int U = 4;   // 256-entry groups in flight per wave
     const uint32_t gend = q1c >> 6;   // chunk ranges are multiples of 256 entries = 64 quads (k_align_chunks)
@@ -688,6 +694,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     };
     uint32_t g0 = (q0c >> 6) + wave * U;
     if (g0 < gend) issue_loads(g0, lc, gw, w);
+    if constexpr (PREFETCH) {
+        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
+        __syncthreads();
+    }
     while (g0 < gend) {
         const uint32_t gn = g0 + NW * U;
         if (gn < gend) issue_loads(gn, nlc, ngw, nw);
