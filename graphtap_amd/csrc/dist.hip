@@ -44,6 +44,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;   // optional (diagnostics)
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                // optional: tears the communicator down after a deadline passed
 };
 Rccl *rccl() {
     static Rccl r;
@@ -61,7 +62,7 @@ Rccl *rccl() {
 #define GT_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, sym)
         GT_SYM(GetUniqueId, "ncclGetUniqueId"); GT_SYM(CommInitRank, "ncclCommInitRank"); GT_SYM(CommDestroy, "ncclCommDestroy");
         GT_SYM(GroupStart, "ncclGroupStart"); GT_SYM(GroupEnd, "ncclGroupEnd"); GT_SYM(Send, "ncclSend"); GT_SYM(Recv, "ncclRecv");
-        GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GetErrorString, "ncclGetErrorString"); GT_SYM(CommCount, "ncclCommCount");
+        GT_SYM(AllReduce, "ncclAllReduce"); GT_SYM(GetErrorString, "ncclGetErrorString"); GT_SYM(CommCount, "ncclCommCount"); GT_SYM(CommAbort, "ncclCommAbort");
 #undef GT_SYM
         if (!(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce && r.GetErrorString)) r.lib = nullptr;
     });
@@ -256,6 +257,7 @@ struct gt_dist {
     // RCCL
     ncclComm_t comm = nullptr;
     bool own_comm = false;
+    bool dead = false;              // a deadline passed: the communicator was aborted, every later collective fails at once
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr;
     std::vector<hipEvent_t> ev_slice, ev_pack;
@@ -359,15 +361,22 @@ static inline bool block_sparse(uint32_t count, uint32_t len) { return len != 0 
 // waits for a stream with a deadline: an exchange that never completes (a peer died, a plan went wrong) must end the run with a
 // message, not hang it (GRAPHTAP_DIST_TIMEOUT_S, default 300)
 int sync_deadline(gt_dist *d, hipStream_t s, const char *what) {
-    static const double limit = getenv("GRAPHTAP_DIST_TIMEOUT_S") ? atof(getenv("GRAPHTAP_DIST_TIMEOUT_S")) : 300.0;
+    if (d->dead) { gt_set_error("rank %d: the communicator was aborted after an earlier deadline; no further collective runs on it", d->rank); return GT_ERR_TIMEOUT; }
+    const double limit = gt_wait_limit_s();   // GRAPHTAP_TIMEOUT_S, else GRAPHTAP_DIST_TIMEOUT_S, default 300 s
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return GT_OK;
         if (e != hipErrorNotReady) { gt_set_error("rank %d: %s failed: %s", d->rank, what, hipGetErrorString(e)); return GT_ERR_HIP; }
         if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
-            gt_set_error("rank %d of %d: %s did not complete within %.0f s (a peer gone, or an exchange that does not match its plan)", d->rank, d->nranks, what, limit);
-            return GT_ERR_HIP;
+            // The RCCL kernel this stream waits for would also block every hipFree / hipDeviceSynchronize of the error path
+            // (gt_graph_free, the scratch pool): the communicator is aborted first, which ends its kernels, so that the error
+            // can be reported at all.
+            if (!d->loop && d->comm && d->own_comm && rccl() && rccl()->CommAbort) { (void)rccl()->CommAbort(d->comm); d->comm = nullptr; }   // (a communicator handed in by the caller is the caller's to abort)
+            d->dead = true;
+            gt_set_error("rank %d of %d: %s did not complete within %g s (a peer gone, or an exchange that does not match its plan); the communicator was aborted",
+                         d->rank, d->nranks, what, limit);
+            return GT_ERR_TIMEOUT;
         }
     }
 }
@@ -755,7 +764,14 @@ int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::
         bool from_pairs = all_pairs && spm != 0 && total < 0x7FFFFFFFull && (spm == 1 || total * 8 <= g->info.nnz_local / frac);
         if (!from_pairs) { st = fill_pair_blocks(d, p, s); if (st != GT_OK) return st; }
         st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
-        st = exchange_issue(d, p, s, from_pairs); if (st != GT_OK) return st;
+        // ONE grouped round for all K slices when every block of every rank travels as pairs (or is empty). The shape of the
+        // exchange must be the same on every rank -- a rank with all its sends in one group against peers with K groups can
+        // leave a peer's later group waiting behind an earlier one: a wait cycle at P > 2 -- so it is derived from the
+        // all-reduced words, which every rank holds identically, never from what this rank alone received. (What a rank DOES
+        // with its pairs -- the SpMSpV straight from them, or scattering them into x -- stays its own choice.)
+        bool one_round = true;
+        for (size_t i = 2; i < d->h_words.size() && one_round; i++) one_round = ((d->h_words[i] >> 32) & 1ull) != 0 || (uint32_t)d->h_words[i] == 0;
+        st = exchange_issue(d, p, s, one_round); if (st != GT_OK) return st;
         if (from_pairs) {
             bool done = false;
             static const uint64_t exact_from = getenv("GRAPHTAP_DIST_EXACT_FROM") ? (uint64_t)atoll(getenv("GRAPHTAP_DIST_EXACT_FROM")) : 4096;   // pairs above which the entries are counted first

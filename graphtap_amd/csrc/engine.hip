@@ -669,7 +669,12 @@ static int init_common(gt_program *p) {
     hipStream_t s = p->stream;
     static std::atomic<uint64_t> epoch_counter{0};   // unique across programs: a freed program's address may be reused
     p->iteration = 0; p->converged = false; p->check_sticky = false; p->init_epoch = ++epoch_counter; p->rowless_reset = false; p->x_fresh = false;
-    if (p->f32_capable && !p->x_f32) { p->x_f32 = true; p->x_bytes = 4; }   // back to the f32 messages a converge-mode run had left (gt_program_prepare)
+    if (p->f32_capable && !p->x_f32) {   // back to the f32 messages a converge-mode run had left (gt_program_prepare)
+        // buffers a driver installed hold (and are exchanged as) the OTHER width: they are taken back, as prepare() requires of
+        // its caller -- the driver asks for the buffers again (graphtap_amd/vertex_program.py drops its tensors in initialize())
+        p->x = p->x_own; p->send = p->send_own;
+        p->x_f32 = true; p->x_bytes = 4;
+    }
     p->last_active = (p->prm.kind == GT_BFS || p->prm.kind == GT_SSSP) ? 1 : ~0ull;   // the root alone is active (bfs.h:37-50, sssp.h:33-42)
     switch (p->prm.kind) {
         case GT_DEG:  // deg.h:31-34
@@ -915,7 +920,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
             // the pairs recorded so far are folded into a running sum and their events used again (a drain of the stream every
             // 32 SpMVs; no event is created inside the iteration loop). Only at a pair boundary: a sliced SpMV holds one open.
             if ((p->ev_used & 1) == 0) {
-                GT_HIP(hipStreamSynchronize(s));
+                { int st = gt_stream_wait_deadline(s, "the iteration loop (timing events)"); if (st != GT_OK) return st; }
                 for (size_t i = 0; i + 1 < p->ev_used; i += 2) { float ms = 0; GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1])); p->ev_acc_ms += ms; p->ev_acc_pairs++; }
                 p->ev_used = 0;
             } else { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
@@ -1165,17 +1170,36 @@ int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hi
     static const bool plain = getenv("GRAPHTAP_PLAIN_READBACK") != nullptr;   // A/B: pageable copy + hipStreamSynchronize
     if (plain || !p->h_pinned || bytes > 256) {
         GT_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
-        GT_HIP(hipStreamSynchronize(s));
-        return GT_OK;
+        return gt_stream_wait_deadline(s, "the per-iteration read-back");
     }
     GT_HIP(hipMemcpyAsync(p->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s));
-    for (;;) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) { gt_set_error("stream failed while reading back %zu bytes: %s", bytes, hipGetErrorString(e)); return GT_ERR_HIP; }
-    }
+    { int st = gt_stream_wait_deadline(s, "the per-iteration read-back"); if (st != GT_OK) return st; }
     memcpy(dst, p->h_pinned, bytes);
     return GT_OK;
+}
+
+// Spins on a stream with a deadline (GRAPHTAP_TIMEOUT_S, else GRAPHTAP_DIST_TIMEOUT_S, default 300 s; read at every call so
+// that a test can shorten it): a kernel that never finishes ends execute() with GT_ERR_TIMEOUT and a message -- never a
+// hang with a core at 100 %, never a re-exec. The stream is left as it is (its work may still complete); the caller's handles
+// stay valid for gt_program_free / gt_graph_free only after the device has drained.
+double gt_wait_limit_s(void) {
+    const char *e = getenv("GRAPHTAP_TIMEOUT_S");
+    if (!e) e = getenv("GRAPHTAP_DIST_TIMEOUT_S");
+    const double v = e ? atof(e) : 300.0;
+    return v > 0 ? v : 300.0;
+}
+int gt_stream_wait_deadline(hipStream_t s, const char *what) {
+    const double limit = gt_wait_limit_s();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return GT_OK;
+        if (e != hipErrorNotReady) { gt_set_error("stream failed during %s: %s", what, hipGetErrorString(e)); return GT_ERR_HIP; }
+        if ((spins & 255u) == 255u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            gt_set_error("%s did not complete within %g s (GRAPHTAP_TIMEOUT_S): a kernel that does not finish, or a device that is gone", what, limit);
+            return GT_ERR_TIMEOUT;
+        }
+    }
 }
 
 int gt_program_apply(gt_program *p, uint32_t num_iterations, uint64_t *active) {
@@ -1220,7 +1244,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->tail_iters = 0; p->spmspv_allocs = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_stream_wait_deadline(s, "the work queued before execute()"); if (st != GT_OK) return st; }
     const uint32_t val_allocs0 = gt_pb_val_allocs(p->g);
     const size_t ev0 = p->ev.size();
     auto t0 = std::chrono::steady_clock::now();
@@ -1232,7 +1256,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     uint32_t samples = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc, double &sq) -> int {
-        if (phase_timing) GT_HIP(hipStreamSynchronize(s));
+        if (phase_timing) { int st = gt_stream_wait_deadline(s, "a phase of the iteration loop (GRAPHTAP_TIMING)"); if (st != GT_OK) return st; }
         auto t2 = now(); const double ms = std::chrono::duration<double, std::milli>(t2 - t).count(); acc += ms; sq += ms * ms; t = t2;
         return GT_OK;
     };
@@ -1259,7 +1283,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
             }
         } else if (p->iteration >= iters) break;
     }
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_stream_wait_deadline(s, "the iteration loop of execute()"); if (st != GT_OK) return st; }   // every wait of execute() has a deadline
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -34,6 +34,12 @@ inline gt_alloc_clock &gt_alloc_clock_ref() { static gt_alloc_clock c; return c;
 // from a POOL: a freed block is kept and handed to the next request it fits (same size or up to 2x larger -- the builds ask for
 // the same few sizes, nnz x 4 / 8, again and again), and the pool is emptied when the graph is built (gt_scratch_release).
 // A multi-GB hipMalloc stalls for seconds now and then on this pool: the fewer of them, the smaller that exposure.
+// Two invariants the pool relies on (both hold for every caller: gt_ingest, gt_layout_build, gt_pb_build, gt_tcsc_cf build):
+//  * one build = one host thread from its first scratch allocation to gt_scratch_release (the pool is thread_local ON PURPOSE:
+//    the loopback ranks of tests/ build their graphs side by side, one host thread each, and must not hand each other blocks);
+//    a block is never freed on another thread than the one that took it;
+//  * every kernel that touches a scratch block runs on the NULL stream, so a block handed out again (without hipFree's implicit
+//    device sync) is reused strictly after its previous user's kernels in stream order.
 struct gt_scratch_pool { struct Blk { void *p; uint64_t bytes; bool busy; }; std::vector<Blk> blocks; uint64_t reused = 0; };
 inline gt_scratch_pool &gt_scratch_pool_ref() { static thread_local gt_scratch_pool pool; return pool; }
 inline hipError_t gt_scratch_malloc(void **p, uint64_t bytes) {
@@ -322,6 +328,10 @@ int gt_bu_maps_init(gt_program *p, hipStream_t s);   // BFS initialize(): both r
 // A few words from the device, once per iteration (the active count, a frontier's entry count): through the program's pinned
 // buffer and a spin on the stream instead of a pageable copy + hipStreamSynchronize (engine.hip)
 extern "C" int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hipStream_t s);   // (inside engine.hip's extern "C" block; not part of the ABI header)
+// Every wait of an iteration loop goes through this: a spin on the stream with a deadline (GRAPHTAP_TIMEOUT_S, else
+// GRAPHTAP_DIST_TIMEOUT_S, default 300 s; read per call). GT_ERR_TIMEOUT + a message when it passes (engine.hip)
+extern "C" int gt_stream_wait_deadline(hipStream_t s, const char *what);
+extern "C" double gt_wait_limit_s(void);
 bool gt_frontier_list_worth(const gt_program *p, uint64_t n);   // kernels.hip
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)
 bool gt_list_spmspv_likely(const gt_program *p);   // the frontier is a short list and the messenger would be a full pass (kernels.hip)

@@ -357,6 +357,23 @@ __global__ void k_segment_vectors(const uint8_t *__restrict__ rowflag, const uin
         if ((buf).alloc(bytes)) { gt_set_error("ingest: out of device memory (%llu bytes)", (unsigned long long)(bytes)); return GT_ERR_HIP; } \
     } while (0)
 
+// Distributed build: a rank that fails ALONE (an out-of-range record in its share, an allocation that only it could not get)
+// must not leave its peers inside the next collective until the deadline: before every collective stage the ranks sum a
+// status word and return the error TOGETHER. `local` = this rank's status of the stage just finished; the failing rank keeps
+// its own message, the others say who failed. A null `dist` is the replicated build (every rank sees the same records and
+// fails the same way): nothing to agree on.
+static int ing_agree(gt_dist *dist, int local, const char *stage) {
+    if (!dist) return local;
+    const int P = gt_dist_nranks(dist), me = gt_dist_rank(dist);
+    std::vector<uint64_t> w((size_t)P, 0);
+    if (local != GT_OK) w[(size_t)me] = (uint64_t)(uint32_t)(-local);
+    { int st = gt_dist_all_reduce_sum_u64_host(dist, w.data(), (uint32_t)P); if (st != GT_OK) return local != GT_OK ? local : st; }
+    if (local != GT_OK) return local;
+    for (int q = 0; q < P; q++)
+        if (w[(size_t)q]) { gt_set_error("distributed build: rank %d failed while %s (status %d); every rank returns", q, stage, -(int)w[(size_t)q]); return -(int)w[(size_t)q]; }
+    return GT_OK;
+}
+
 int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_dist *dist) {
     const gt_graph_flags f = g->flags;
     const uint32_t p = g->info.nranks, k = g->info.rank, H = g->info.tile_height, nrows = g->info.nrows;
@@ -376,74 +393,91 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_d
         GT_REQUIRE(multi, GT_ERR_STATE, "the distributed build needs the exchange layout");
         GT_REQUIRE(gt_dist_nranks(dist) == (int)p && gt_dist_rank(dist) == (int)k, GT_ERR_INVALID, "the communicator and the graph disagree on rank / nranks");
         DevBuf cnt_d, base_d, cur_d, sendbuf;
-        ING_ALLOC(cnt_d, p * 8); ING_ALLOC(base_d, p * 8); ING_ALLOC(cur_d, p * 8);
-        ING_HIP(hipMemsetAsync(cnt_d.p, 0, p * 8, s)); ING_HIP(hipMemsetAsync(cur_d.p, 0, p * 8, s));
-        const unsigned rgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, 256u * 16u));
-        if (m) k_route_count<<<rgrid, 256, p * 4, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p, cnt_d.as<unsigned long long>());
         std::vector<uint64_t> scount(p), soff(p), rcount(p), roff(p), matrix((size_t)p * p, 0);
-        ING_HIP(hipMemcpyAsync(scount.data(), cnt_d.p, p * 8, hipMemcpyDeviceToHost, s));
-        ING_HIP(hipStreamSynchronize(s));
-        uint64_t stotal = 0;
+        const unsigned rgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, 256u * 16u));
+        uint64_t stotal = 0, rtotal = 0;
+        const uint64_t rb = (uint64_t)stride * 4;
+        // every rank-local stage is a lambda whose status the ranks agree on before the collective that follows it (ing_agree)
+        int local = [&]() -> int {
+            ING_ALLOC(cnt_d, p * 8); ING_ALLOC(base_d, p * 8); ING_ALLOC(cur_d, p * 8);
+            ING_HIP(hipMemsetAsync(cnt_d.p, 0, p * 8, s)); ING_HIP(hipMemsetAsync(cur_d.p, 0, p * 8, s));
+            if (m) k_route_count<<<rgrid, 256, p * 4, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p, cnt_d.as<unsigned long long>());
+            ING_HIP(hipMemcpyAsync(scount.data(), cnt_d.p, p * 8, hipMemcpyDeviceToHost, s));
+            ING_HIP(hipStreamSynchronize(s));
+            return GT_OK;
+        }();
+        { int st = ing_agree(dist, local, "counting where its records go"); if (st != GT_OK) return st; }
         for (uint32_t q = 0; q < p; q++) { soff[q] = stotal; stotal += scount[q]; matrix[(size_t)k * p + q] = scount[q]; }
         { int st = gt_dist_all_reduce_sum_u64_host(dist, matrix.data(), p * p); if (st != GT_OK) return st; }   // everybody learns every count
-        uint64_t rtotal = 0;
         for (uint32_t q = 0; q < p; q++) { rcount[q] = matrix[(size_t)q * p + k]; roff[q] = rtotal; rtotal += rcount[q]; }
-        const uint64_t rb = (uint64_t)stride * 4;
-        ING_ALLOC(sendbuf, std::max<uint64_t>(stotal, 1) * rb); ING_ALLOC(shuffled_buf, std::max<uint64_t>(rtotal, 1) * rb);
-        ING_HIP(hipMemcpyAsync(base_d.p, soff.data(), p * 8, hipMemcpyHostToDevice, s));
-        if (m) k_route_fill<<<rgrid, 256, ((p + 1) & ~1u) * 4 + p * 8, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p,
-                                                                            base_d.as<unsigned long long>(), cur_d.as<unsigned long long>(), sendbuf.as<uint32_t>());
-        ING_HIP(hipGetLastError());
+        local = [&]() -> int {
+            ING_ALLOC(sendbuf, std::max<uint64_t>(stotal, 1) * rb); ING_ALLOC(shuffled_buf, std::max<uint64_t>(rtotal, 1) * rb);
+            ING_HIP(hipMemcpyAsync(base_d.p, soff.data(), p * 8, hipMemcpyHostToDevice, s));
+            if (m) k_route_fill<<<rgrid, 256, ((p + 1) & ~1u) * 4 + p * 8, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, k, p,
+                                                                                base_d.as<unsigned long long>(), cur_d.as<unsigned long long>(), sendbuf.as<uint32_t>());
+            ING_HIP(hipGetLastError());
+            return GT_OK;
+        }();
+        { int st = ing_agree(dist, local, "packing its records for the shuffle"); if (st != GT_OK) return st; }
         std::vector<uint64_t> sob(p), scb(p), rob(p), rcb(p);
         for (uint32_t q = 0; q < p; q++) { sob[q] = soff[q] * rb; scb[q] = scount[q] * rb; rob[q] = roff[q] * rb; rcb[q] = rcount[q] * rb; }
         { int st = gt_dist_exchange_bytes(dist, sendbuf.p, sob.data(), scb.data(), shuffled_buf.p, rob.data(), rcb.data(), s); if (st != GT_OK) return st; }
         edges_dev = shuffled_buf.p; m = rtotal;
     }
     const uint64_t cap = m * slots;
-
     DevBuf keys, keys2, wts, wts2, rowflag, colflag, Srow, Scol, counters, tmp, needme, needby, Sneed, Sby, Pneed, Pby;
-    // Room for the kept entries: everything on one rank; on several, the hashed id space spreads the entries evenly, so
-    // 1.25 x the mean share (+ slack for small graphs) is reserved and the pass is repeated with the exact count in the
-    // rare case it does not fit (a multi-GB hipMalloc is not free: 8.6 GB for every rank of 8 at R-MAT-26 otherwise).
-    uint64_t room = (p == 1 || dist) ? cap : std::min<uint64_t>(cap, cap / p + cap / (4 * p) + 65536);   // (after the shuffle every record is mine)
-    ING_ALLOC(keys, room * 8);
-    if (weighted) ING_ALLOC(wts, room * 4);
-    ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
-    ING_ALLOC(Srow, (span + 1) * 4); ING_ALLOC(Scol, (span + 1) * 4);
-    ING_ALLOC(counters, 8 * sizeof(unsigned long long));
-    ING_HIP(hipMemsetAsync(rowflag.p, 0, span + 1, s));
-    ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
-    ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
-    if (multi) {
-        ING_ALLOC(needme, (span + 1) * 4); ING_ALLOC(needby, (span + 1) * 4);
-        ING_ALLOC(Sneed, (span + 1) * 4); ING_ALLOC(Sby, (span + 1) * 4);
-        ING_ALLOC(Pneed, (span + 1) * 4); ING_ALLOC(Pby, (span + 1) * 4);
-        ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s));
-        ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s));
-    }
-
+    uint64_t room = 0;
     unsigned long long hc[3] = {0, 0, 0};
-    for (int attempt = 0; attempt < 2 && m; attempt++) {
-        k_expand<<<(unsigned)std::min<uint64_t>((m + EXPAND_TPB - 1) / EXPAND_TPB, 256u * 8u), EXPAND_TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
-                                             keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
-                                             rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
-                                             multi ? needme.as<uint32_t>() : nullptr, (multi && !dist) ? needby.as<uint32_t>() : nullptr,
-                                             counters.as<unsigned long long>(), dist != nullptr);
-        ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
-        ING_HIP(hipStreamSynchronize(s));
-        if (hc[0] <= room) break;
-        // did not fit (nothing was written past `room`): exact size, second pass (flags are idempotent, the counts start over)
-        if (multi) { ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s)); ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s)); }
-        room = hc[0];
-        gt_scratch_free(keys.p); keys.p = nullptr; ING_ALLOC(keys, room * 8);
-        if (weighted) { gt_scratch_free(wts.p); wts.p = nullptr; ING_ALLOC(wts, room * 4); }
+    // (a lambda: on several ranks with a distributed build its status is agreed on before the collectives that follow)
+    int expand_status = [&]() -> int {
+
+        // Room for the kept entries: everything on one rank; on several, the hashed id space spreads the entries evenly, so
+        // 1.25 x the mean share (+ slack for small graphs) is reserved and the pass is repeated with the exact count in the
+        // rare case it does not fit (a multi-GB hipMalloc is not free: 8.6 GB for every rank of 8 at R-MAT-26 otherwise).
+        room = (p == 1 || dist) ? cap : std::min<uint64_t>(cap, cap / p + cap / (4 * p) + 65536);   // (after the shuffle every record is mine)
+        ING_ALLOC(keys, room * 8);
+        if (weighted) ING_ALLOC(wts, room * 4);
+        ING_ALLOC(rowflag, span + 1); ING_ALLOC(colflag, span + 1);
+        ING_ALLOC(Srow, (span + 1) * 4); ING_ALLOC(Scol, (span + 1) * 4);
+        ING_ALLOC(counters, 8 * sizeof(unsigned long long));
+        ING_HIP(hipMemsetAsync(rowflag.p, 0, span + 1, s));
+        ING_HIP(hipMemsetAsync(colflag.p, 0, span + 1, s));
         ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
-    }
-    if (hc[1]) {
-        gt_set_error("%llu edge record(s) name a vertex id > num_vertices=%u (the reference overflows its tile grid silently, "
-                     "src/mat/matrix.hpp:218-220; this library rejects the input)", hc[1], g->info.num_vertices);
-        return GT_ERR_INVALID;
-    }
+        if (multi) {
+            ING_ALLOC(needme, (span + 1) * 4); ING_ALLOC(needby, (span + 1) * 4);
+            ING_ALLOC(Sneed, (span + 1) * 4); ING_ALLOC(Sby, (span + 1) * 4);
+            ING_ALLOC(Pneed, (span + 1) * 4); ING_ALLOC(Pby, (span + 1) * 4);
+            ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s));
+            ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s));
+        }
+
+        for (int attempt = 0; attempt < 2 && m; attempt++) {
+            k_expand<<<(unsigned)std::min<uint64_t>((m + EXPAND_TPB - 1) / EXPAND_TPB, 256u * 8u), EXPAND_TPB, 0, s>>>((const uint32_t *)edges_dev, m, stride, f, nrows, g->perm_a, g->perm_mask, H, row_lo, row_hi,
+                                                 keys.as<uint64_t>(), weighted ? wts.as<uint32_t>() : nullptr, room,
+                                                 rowflag.as<uint8_t>(), colflag.as<uint8_t>(),
+                                                 multi ? needme.as<uint32_t>() : nullptr, (multi && !dist) ? needby.as<uint32_t>() : nullptr,
+                                                 counters.as<unsigned long long>(), dist != nullptr);
+            ING_HIP(hipMemcpyAsync(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost, s));
+            ING_HIP(hipStreamSynchronize(s));
+            if (hc[0] <= room) break;
+            // did not fit (nothing was written past `room`): exact size, second pass (flags are idempotent, the counts start over)
+            if (multi) { ING_HIP(hipMemsetAsync(needme.p, 0, (span + 1) * 4, s)); ING_HIP(hipMemsetAsync(needby.p, 0, (span + 1) * 4, s)); }
+            room = hc[0];
+            gt_scratch_free(keys.p); keys.p = nullptr; ING_ALLOC(keys, room * 8);
+            if (weighted) { gt_scratch_free(wts.p); wts.p = nullptr; ING_ALLOC(wts, room * 4); }
+            ING_HIP(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), s));
+        }
+        if (hc[1]) {
+            gt_set_error("%llu edge record(s) name a vertex id > num_vertices=%u (the reference overflows its tile grid silently, "
+                         "src/mat/matrix.hpp:218-220; this library rejects the input)", hc[1], g->info.num_vertices);
+            return GT_ERR_INVALID;
+        }
+        GT_REQUIRE(hc[0] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED,
+                   "tile-row holds %llu entries; column pointers are 32-bit like the reference's Integer_Type "
+                   "(src/ds/compressed_column.hpp:294): use more ranks", (unsigned long long)hc[0]);
+        return GT_OK;
+    }();
+    { int st = ing_agree(dist, expand_status, "expanding its records into entries"); if (st != GT_OK) return st; }
     if (dist) {
         // the global pieces, from collectives: a column is non-empty if ANY tile-row has an entry in it; what tile-row q has in MY
         // columns (the order of my send blocks) is q's own count over my segment

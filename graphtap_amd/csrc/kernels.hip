@@ -905,7 +905,7 @@ static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
     unsigned long long cnt[2] = {0, 0}; unsigned int n = 0;   // entries of the unreached rows' columns, of the frontier's columns
     GT_HIP(hipMemcpyAsync(cnt, p->d_frontier + 1, sizeof(cnt), hipMemcpyDeviceToHost, s));
     GT_HIP(hipMemcpyAsync(&n, p->d_fl + 3, sizeof(n), hipMemcpyDeviceToHost, s));
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_stream_wait_deadline(s, "the bottom-up collecting pass"); if (st != GT_OK) return st; }
     const uint64_t nnz = g->info.nnz_local, entries = cnt[0], fe = cnt[1];
     // Looking at every entry of the unreached rows pays when they are few (nnz / 8: the push sweep costs a pass over the active
     // windows). With early exit a row probes ~nnz / fe entries before its first hit (fe = entries of the frontier's columns = the
@@ -975,7 +975,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     k_frontier_count<<<grid, TPB, 0, s>>>((const uint32_t *)p->x, x_len, g->xcol, g->JA, p->d_frontier);
     unsigned long long h[2] = {0, 0};
     GT_HIP(hipMemcpyAsync(h, p->d_frontier, sizeof(h), hipMemcpyDeviceToHost, s));
-    GT_HIP(hipStreamSynchronize(s));
+    { int st = gt_stream_wait_deadline(s, "the frontier count"); if (st != GT_OK) return st; }
     if (h[0] == 0 || h[1] == 0) { *done = true; return GT_OK; }  // empty frontier (or active columns without entries here): y keeps its running minima
     // The reference switches at 0.6 of the columns (vp:769). Here the streaming pass already skips every window without an
     // active column (pb.hip), so the frontier-driven kernels only pay for small frontiers; this scan-based entry is what is left

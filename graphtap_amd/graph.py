@@ -97,34 +97,44 @@ class Graph:
                            parallel_edges, compression_type, rank, nranks)
 
     def load_share(self, dist_handle, rank, nranks, edges_share, nrows, ncols, directed=True, transpose=False, self_loops=True, acyclic=False,
-                   parallel_edges=True, tiling_type=_2DT_, compression_type=_TCSC_):
+                   parallel_edges=True, tiling_type=_2DT_, compression_type=_TCSC_, m_share=None):
         """Matrix::distribute (mat/matrix.hpp:693-810): this rank's SHARE of the edge list (any split; host array [m, 2 or 3] of
-        uint32); the build shuffles the records to the owners of their rows over the communicator. Collective: every rank
-        of `dist_handle` (a gt_dist; `rank` / `nranks` are its) calls it."""
-        edges = np.ascontiguousarray(edges_share, dtype=np.uint32)
-        if nrows != ncols:
-            raise GraphTapError("GraphTap graphs are square")
+        uint32, or -- with `m_share` -- the address of that many records already in HBM); the build shuffles the records to the
+        owners of their rows over the communicator. Collective: every rank of `dist_handle` (a gt_dist; `rank` / `nranks`
+        are its) calls it."""
+        self._validate(nrows, ncols, compression_type)
+        if m_share is None:
+            edges = np.ascontiguousarray(edges_share, dtype=np.uint32)
+            ptr, m, on_device = edges.ctypes.data_as(C.c_void_p), edges.shape[0], 0
+        else:
+            ptr, m, on_device = C.c_void_p(int(edges_share)), int(m_share), 1
         self.free()
         self.rank, self.nranks = rank, nranks
         self.exchange = nranks > 1 or os.environ.get("GRAPHTAP_FORCE_EXCHANGE", "0") not in ("", "0")
         self.tiling_type, self.compression_type = tiling_type, compression_type
         self.flags = GraphFlags(int(directed), int(transpose), int(self_loops), int(acyclic), int(parallel_edges))
         h = C.c_void_p()
-        check(lib().gt_graph_build_distributed(C.byref(h), dist_handle, edges.ctypes.data_as(C.c_void_p), edges.shape[0], 0, int(self.weighted),
+        check(lib().gt_graph_build_distributed(C.byref(h), dist_handle, ptr, m, on_device, int(self.weighted),
                                                int(nrows), C.byref(self.flags)))
         self._h = h
         self.info = GraphInfo()
         check(lib().gt_graph_info_get(self._h, C.byref(self.info)))
-        self.nnz_global = int(self.info.nnz_local)
-        self.nnzrows_global = int(self.info.nnzrows_global)
+        # the TEPS denominators and display() are global figures: summed over the communicator the build ran on
+        w = (C.c_uint64 * 2)(int(self.info.nnz_local), int(self.info.nnzrows))
+        check(lib().gt_dist_all_reduce_u64(dist_handle, w, 2))
+        self.nnz_global, self.nnzrows_global = int(w[0]), int(w[1])
         return self
 
-    def _build(self, ptr, m, on_device, nrows, ncols, directed, transpose, self_loops, acyclic, parallel_edges,
-               compression_type, rank, nranks):
+    @staticmethod
+    def _validate(nrows, ncols, compression_type):
         if nrows != ncols:
             raise GraphTapError("square matrices only (every reference app passes num_vertices twice)")
         if compression_type not in (_TCSC_, _TCSC_CF_):
             raise GraphTapError("only TCSC / TCSC_CF tiles exist in this engine (all reference apps use them)")
+
+    def _build(self, ptr, m, on_device, nrows, ncols, directed, transpose, self_loops, acyclic, parallel_edges,
+               compression_type, rank, nranks):
+        self._validate(nrows, ncols, compression_type)
         if rank is None:
             rank, nranks = world()
         self.free()

@@ -192,13 +192,22 @@ class Vertex_Program:
 
     # -- initialize(), vp:443-464 / initialize(other), vp:466-501
     def initialize(self, other=None):
+        eng = getattr(self, "_engine", None)
+        h = self._handle()
+        w0, w1 = C.c_uint32(), C.c_uint32()
+        check(lib().gt_program_x(h, None, None, C.byref(w0)))
         if other is None:
-            check(lib().gt_program_initialize(self._handle()))
+            check(lib().gt_program_initialize(h))
         else:
-            check(lib().gt_program_initialize_from(self._handle(), other._handle()))
+            check(lib().gt_program_initialize_from(h, other._handle()))
+        check(lib().gt_program_x(h, None, None, C.byref(w1)))
         self._already_initialized = True
-        if getattr(self, "_engine", None) is not None:
-            self._engine.check_sticky = False
+        if eng is not None:
+            eng.check_sticky = False
+            if w0.value != w1.value:
+                # initialize() took a PageRank program back from the f64 messages of a converge-mode run to its f32 ones and
+                # un-installed the driver's buffers (engine.hip, init_common): tensors of the other width must not be exchanged
+                eng._x = eng._send = None
 
     # -- execute(num_iterations = 0), vp:408-441
     def execute(self, num_iterations=0):

@@ -39,7 +39,9 @@ typedef enum gt_status {
     GT_ERR_HIP = -2,        /* a HIP runtime call failed */
     GT_ERR_NO_DEVICE = -3,  /* no gfx950 device visible: the product has no CPU fallback */
     GT_ERR_UNSUPPORTED = -4,
-    GT_ERR_STATE = -5       /* call order violated */
+    GT_ERR_STATE = -5,      /* call order violated */
+    GT_ERR_TIMEOUT = -6     /* a wait inside an iteration loop passed its deadline (GRAPHTAP_TIMEOUT_S, default 300 s): the
+                               library returns with a message instead of spinning for ever; the handles may only be freed */
 } gt_status;
 
 /* program kinds = the reference's five apps (src/apps/{deg,pr,bfs,sssp,cc}.h) */
