@@ -23,7 +23,8 @@ GTEPS = stored entries x K / t / 1e9. roofline.achieved = algorithmi
 SpMV launch / mean SpMV kernel duration measured with HIP events on the launch stream;
 B_alg = 4 nnz + 4 (nnzcols+1) + Fx nnzcols + 8 nnzrows (Fx = 4 with f32 messages, else 8): SpMV bytes only.
 The fused applicator's bytes are reported separately (`frac_with_apply`); `f64_messages` is the all-f64 run of the
-same graph; `measured_ceiling_GBps` is this box's streaming-copy rate.
+same graph, `full_applicator` the run whose applicator stores rank / changed flags in every iteration like the reference's;
+`measured_ceiling_GBps` (1:1 copy), `read_ceiling_GBps` and `mixed_ceiling_GBps` are this box's streaming rates, measured in this run.
 """
 import argparse
 import ctypes as C
@@ -195,15 +196,31 @@ def main():
     m = 16 << scale
     t_in0 = time.perf_counter()
     d = C.c_void_p()
-    _lib.check(L.gt_malloc(C.byref(d), m * 8))
-    _lib.check(L.gt_rmat_generate(d, scale, args.seed, 0, 0, m, None))
     G = gt.Graph()
-    G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=rank, nranks=world)  # apps/pr.cpp:26-36
+    native = dist_on and args.driver == "native" and args.backend == "nccl"
+    if native and os.environ.get("GRAPHTAP_BENCH_REPLICATED_BUILD", "0") in ("", "0"):
+        # Matrix::distribute (mat/matrix.hpp:693-810), the path the application mains take: every rank generates ITS 1/N of the
+        # record stream (the generator is counter based: records [first, first + count) of the same stream) and
+        # gt_graph_build_distributed shuffles the records to the owners of their rows over RCCL. `ingress_s` is then the time of
+        # the distributed build (per rank in `per_rank`), not of N replicated ones.
+        first = m * rank // world
+        count = m * (rank + 1) // world - first
+        _lib.check(L.gt_malloc(C.byref(d), max(count, 1) * 8))
+        _lib.check(L.gt_rmat_generate(d, scale, args.seed, 0, first, count, None))
+        G.load_share(dist_native.handle(), rank, world, d.value, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, m_share=count)
+        build_kind = "distributed: 1/%d of the records per rank, shuffled by gt_graph_build_distributed" % world
+    else:
+        _lib.check(L.gt_malloc(C.byref(d), m * 8))
+        _lib.check(L.gt_rmat_generate(d, scale, args.seed, 0, 0, m, None))
+        G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=rank, nranks=world)  # apps/pr.cpp:26-36
+        build_kind = "replicated: every rank sees all records and keeps its tile-row" if dist_on else "single rank"
     _lib.check(L.gt_free(d))
     V = gt.Deg_Program(G, True, False, False, gt._COL_)   # apps/pr.cpp:37-42
     V.execute(1)
     VR = gt.PR_Program(G, True, False, False, gt._ROW_)   # apps/pr.cpp:46-50
     VR.initialize(V)
+    torch.cuda.synchronize()
+    t_ingress_mine = time.perf_counter() - t_in0   # this rank's own ingress (per_rank); the line's `ingress_s` is up to the barrier
     barrier()
     t_ingress = time.perf_counter() - t_in0
 
@@ -271,15 +288,37 @@ def main():
 
     checksum = VR.checksum(out=None)
     iterations_total = VR.iteration
-    traffic = None
+    # roofline.traffic: HBM bytes per SpMV from the rocprofv3 --pmc passes (profiles/collect_pmc.py). It is a number of the
+    # builder's collection, not of this run -- so it carries where it came from, and it is null as soon as the kernels' source
+    # (graphtap_amd/csrc/pb.hip) is no longer the one the counters were collected from.
+    traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/collect_pmc.py from rocprofv3 --pmc passes
     if os.path.exists(tp):
         try:
-            rec = json.load(open(tp))
-            key = "scale%d_gpus%d" % (scale, world)   # collected for the default variant (pb_f32msg) only
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch") if args.spmv == "pb_f32msg" else None
+            import hashlib
+            rec = json.load(open(tp)).get("scale%d_gpus%d" % (scale, world), {})   # collected for the default variant (pb_f32msg) only
+            sha = hashlib.sha256(open(os.path.join(ROOT, "graphtap_amd", "csrc", "pb.hip"), "rb").read()).hexdigest()[:16]
+            col = rec.get("collected", {})
+            current = col.get("pb_hip_sha16") == sha
+            traffic_source = {"file": "profiles/pmc_traffic.json", "collected": col.get("date"), "commit": col.get("commit"),
+                              "kernel_source_unchanged_since": bool(current)}
+            if args.spmv == "pb_f32msg" and current:
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
+
+    # the like-for-like applicator beside it: the reference's apply_stationary (vp:1641-1693) writes rank and changed flags in
+    # EVERY iteration; the headline run elides the stores nobody can see. Same graph, same variant, full applicator.
+    full_rec = None
+    if world == 1 and not dist_on and lean and not args.no_f64:
+        os.environ["GRAPHTAP_PR_LEAN_STATE"] = "0"
+        try:
+            dt3, kms3, _ = timed_run(VR)
+        finally:
+            del os.environ["GRAPHTAP_PR_LEAN_STATE"]
+        full_rec = {"applicator": "full state every iteration (GRAPHTAP_PR_LEAN_STATE=0)", "spmv": args.spmv, "value": nnz * args.steps / dt3 / 1e9, "unit": "GTEPS",
+                    "ms_per_step": dt3 * 1e3 / args.steps, "kernel_ms": kms3, "frac": b_spmv / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "value_checksum": VR.checksum(out=None)[0], **({"phase_ms": phase_ms[-1]} if phase_ms[-1] else {})}
 
     # the all-f64 path beside it (the reference's fp is double, apps/deg.h:19): same graph, messages kept in f64
     f64_rec = None
@@ -291,23 +330,20 @@ def main():
         dt2, kms2, _ = timed_run(VR)
         f64_rec = {"spmv": "pb", "value": nnz * args.steps / dt2 / 1e9, "unit": "GTEPS", "ms_per_step": dt2 * 1e3 / args.steps, "kernel_ms": kms2,
                    "algorithmic_bytes_spmv": float(b_spmv_of("pb")), "frac": b_spmv_of("pb") / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                   "value_checksum": VR.checksum(out=None)[0], **({"phase_ms": phase_ms[1]} if len(phase_ms) > 1 and phase_ms[1] else {})}
+                   "value_checksum": VR.checksum(out=None)[0], **({"phase_ms": phase_ms[-1]} if len(phase_ms) > 1 and phase_ms[-1] else {})}
 
-    # streaming-copy ceiling of THIS box, measured live (4.7-4.8 TB/s copy against the 8 TB/s spec)
-    ceiling = None
+    # the streaming ceilings of THIS box, measured live with the library's diagnostic kernels (csrc/diag.hip: the shapes of
+    # tools/hbm_ceiling2.hip): DESIGN 4.1's argument -- pure reads run at ~7 TB/s here, ANY read/write mix at ~5.2 -- in the line
+    ceiling, ceilings = None, None
     if world == 1 and not dist_on:
         VR.free(); V.free(); G.free()
-        n = 1 << 29
-        a = torch.empty(n, dtype=torch.float32, device="cuda"); b = torch.ones(n, dtype=torch.float32, device="cuda")
-        a.copy_(b); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            a.copy_(b)
-        e1.record(); torch.cuda.synchronize()
-        ceiling = 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a, b
         torch.cuda.empty_cache()
+        ceilings = {}
+        for name, mode in (("read_nt", 0), ("write", 1), ("copy_1to1", 2), ("mix_3r_2w", 3), ("mix_16r_1w_nt", 4), ("mix_7r_1w_nt", 5)):
+            v = C.c_double()
+            if L.gt_diag_hbm_ceiling(mode, 4 << 30, C.byref(v)) == 0:
+                ceilings[name] = round(v.value, 1)
+        ceiling = ceilings.get("copy_1to1")
     out = {
         "metric": "PageRank GTEPS on RMAT-%d" % scale, "value": value, "unit": "GTEPS", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
@@ -317,16 +353,21 @@ def main():
                    "spmv": args.spmv, "applicator": "rank / changed flags stored by the last two iterations only (dead stores elided; GRAPHTAP_PR_LEAN_STATE=0: every iteration)" if lean else "full state every iteration",
                    "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if dist_on else "single tile",
                    "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if dist_on else "C++ gt_program_execute",
-                   "ingress_s": round(t_ingress, 3), "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
+                   "ingress_s": round(t_ingress, 3), "build": build_kind, "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},
         "roofline": {"bound": "hbm", "kernel": {"pb": "k_pb_scatter* + k_pb_gather<double,double> (one SpMV = this launch group)",
                                                   "pb_f32msg": "k_pb_scatter* + k_pb_gather<double,float> (one SpMV = this launch group)",
                                                   "edge": "k_spmv_edge<GT_PLUS_F64>"}[args.spmv], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": b_spmv,
                      "frac_with_apply": (b_spmv + b_fused) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "algorithmic_bytes_fused_apply": float(b_fused), "fused_apply_rows": fused_rows,
-                     "measured_ceiling_GBps": ceiling, "kernel_ms": kernel_ms, "launches": launches,
+                     "measured_ceiling_GBps": ceiling, "read_ceiling_GBps": (ceilings or {}).get("read_nt"),
+                     "mixed_ceiling_GBps": ({"3:2 (phase 1's mix)": ceilings.get("mix_3r_2w"), "16:1 nt (phase 2's mix, lean applicator)": ceilings.get("mix_16r_1w_nt"),
+                                             "7:1 nt (phase 2's mix, full applicator)": ceilings.get("mix_7r_1w_nt"), "write only": ceilings.get("write")} if ceilings else None),
+                     "kernel_ms": kernel_ms, "launches": launches,
                      **({"phase_ms": phase_ms[0]} if phase_ms and phase_ms[0] else {})},
     }
+    if full_rec is not None:
+        out["full_applicator"] = full_rec
     if f64_rec is not None:
         out["f64_messages"] = f64_rec
     if rank == 0 and world == 1 and not dist_on and not args.no_cpu_baseline:
@@ -340,7 +381,7 @@ def main():
         if args.driver == "native" and args.backend == "nccl":
             mine = dist_native.diagnostics()
             mine.pop("per_iteration", None)
-            mine.update(rank=rank, spmv_kernel_ms=round(float(VR.stats.spmv_ms) / max(int(VR.stats.spmv_launches), 1), 4), nnz_local=int(i.nnz_local),
+            mine.update(rank=rank, ingress_s=round(t_ingress_mine, 3), spmv_kernel_ms=round(float(VR.stats.spmv_ms) / max(int(VR.stats.spmv_launches), 1), 4), nnz_local=int(i.nnz_local),
                         ncols_local=int(i.ncols_local))
             allr = [None] * world
             dist.all_gather_object(allr, mine)

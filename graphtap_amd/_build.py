@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgraphtap_amd.so")
 OBJ = os.path.join(HERE, "lib", "obj")
-SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip", "dist.hip", "tcsc_cf.hip"]
+SOURCES = ["engine.hip", "ingest.hip", "kernels.hip", "pb.hip", "dist.hip", "tcsc_cf.hip", "diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, stale))
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [_obj(s) for s in SOURCES] + ["-ldl"]
     if verbose:

@@ -121,6 +121,7 @@ SIGNATURES = {
     "gt_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64]),
     "gt_memset": (C.c_int, [_vp, C.c_int, C.c_uint64]),
     "gt_device_synchronize": (C.c_int, []),
+    "gt_diag_hbm_ceiling": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -138,7 +139,7 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        if L.gt_abi_version() != 2:
+        if L.gt_abi_version() != 3:
             raise GraphTapError("ABI version mismatch")
         _lib = L
     return _lib

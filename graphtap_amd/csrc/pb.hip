@@ -1208,6 +1208,64 @@ int gt_pb_build(gt_graph *g) {
             fprintf(stderr, "[pb] dense chunks, stretches of up to %u consecutive entries: %llu outputs\n", mask + 1, c);
         }
     }
+    if (stats) {
+        // Where the value-stream slots are: by WINDOW RANK (dense windows are in descending column-degree order, so the window index
+        // is the rank) and by how heavy the row bin is. VERDICT round 3 asked for this table before any scheme that keeps the
+        // heaviest windows' partial sums off HBM: such a scheme saves 10 B per slot of the windows it fuses (4 written + 4 read
+        // + 2 of LROW) and has to stage every fused window once per row bin it meets (W x 4 B from L2 into LDS).
+        std::vector<uint32_t> hk(nrun), hl(nrun), ho(nrun), hc(nchunks);
+        PB_HIP(hipMemcpy(hk.data(), runkey.p, (uint64_t)nrun * 4, hipMemcpyDeviceToHost));
+        PB_HIP(hipMemcpy(hl.data(), len.p, (uint64_t)nrun * 4, hipMemcpyDeviceToHost));
+        PB_HIP(hipMemcpy(ho.data(), noutpad.p, (uint64_t)nrun * 4, hipMemcpyDeviceToHost));
+        PB_HIP(hipMemcpy(hc.data(), pb->ccol0, (uint64_t)nchunks * 4, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> we(geom.nwin, 0), ws(geom.nwin, 0), wruns(geom.nwin, 0), be(pb->nbins, 0), bs(pb->nbins, 0);
+        for (uint32_t r = 0; r < nrun; r++) {
+            const uint32_t c = hk[r] >> binbits, b = hk[r] & binmask, q = win_of(geom, hc[c]);
+            we[q] += hl[r]; ws[q] += ho[r]; wruns[q]++; be[b] += hl[r]; bs[b] += ho[r];
+        }
+        // bins by slot count, heaviest first: class 0 = the heaviest 1 %, 1 = the next 9 %, 2 = the rest
+        std::vector<uint32_t> border(pb->nbins);
+        for (uint32_t b = 0; b < pb->nbins; b++) border[b] = b;
+        std::sort(border.begin(), border.end(), [&](uint32_t a, uint32_t b) { return bs[a] > bs[b]; });
+        std::vector<uint8_t> bclass(pb->nbins, 2);
+        for (uint32_t i = 0; i < pb->nbins; i++) bclass[border[i]] = i < (pb->nbins + 99) / 100 ? 0 : i < (pb->nbins + 9) / 10 ? 1 : 2;
+        const uint32_t edges_[] = {0, 1, 4, 16, 64, 256, geom.ndw};   // window-rank classes among the dense windows, then the sparse ones
+        struct Cls { const char *name; uint32_t lo, hi; } cls[8];
+        int ncl = 0;
+        static char names[8][40];
+        for (int i = 0; i + 1 < 7; i++) {
+            const uint32_t lo = std::min(edges_[i], geom.ndw), hi = std::min(edges_[i + 1], geom.ndw);
+            if (hi <= lo) continue;
+            snprintf(names[ncl], sizeof(names[ncl]), "dense windows %u..%u", lo, hi - 1);
+            cls[ncl] = Cls{names[ncl], lo, hi}; ncl++;
+        }
+        snprintf(names[ncl], sizeof(names[ncl]), "sparse windows (%u)", geom.nwin - geom.ndw);
+        cls[ncl] = Cls{names[ncl], geom.ndw, geom.nwin}; ncl++;
+        std::vector<uint64_t> ce(ncl * 3, 0), cs(ncl * 3, 0);
+        for (uint32_t r = 0; r < nrun; r++) {
+            const uint32_t c = hk[r] >> binbits, b = hk[r] & binmask, q = win_of(geom, hc[c]);
+            for (int k = 0; k < ncl; k++) if (q >= cls[k].lo && q < cls[k].hi) { ce[k * 3 + bclass[b]] += hl[r]; cs[k * 3 + bclass[b]] += ho[r]; }
+        }
+        fprintf(stderr, "[pb] slots by window rank (value-stream round trip = 10 B per slot; fusing a window into phase 2 = one staging of %u B per row bin = %.1f MB of L2->LDS per window)\n",
+                W * 4, (double)pb->nbins * W * 4 / 1e6);
+        fprintf(stderr, "[pb] %-28s %8s %12s %12s %8s %10s %12s | slots in the heaviest 1%% / next 9%% / other bins\n", "class", "windows", "entries", "slots", "e/slot", "saved MB", "staged MB");
+        uint64_t te = 0, ts = 0;
+        for (int k = 0; k < ncl; k++) {
+            uint64_t e = 0, sl = 0;
+            for (uint32_t q = cls[k].lo; q < cls[k].hi; q++) { e += we[q]; sl += ws[q]; }
+            te += e; ts += sl;
+            fprintf(stderr, "[pb] %-28s %8u %12llu %12llu %8.2f %10.1f %12.1f | %llu / %llu / %llu\n", cls[k].name, cls[k].hi - cls[k].lo, (unsigned long long)e, (unsigned long long)sl,
+                    sl ? (double)e / sl : 0.0, sl * 10.0 / 1e6, (double)(cls[k].hi - cls[k].lo) * pb->nbins * W * 4 / 1e6,
+                    (unsigned long long)cs[k * 3], (unsigned long long)cs[k * 3 + 1], (unsigned long long)cs[k * 3 + 2]);
+        }
+        fprintf(stderr, "[pb] %-28s %8u %12llu %12llu\n", "all", geom.nwin, (unsigned long long)te, (unsigned long long)ts);
+        for (uint32_t q = 0; q < std::min(geom.ndw, 8u); q++)
+            fprintf(stderr, "[pb] window %u: %llu entries, %llu slots (%.1f per slot), %llu runs\n", q, (unsigned long long)we[q], (unsigned long long)ws[q], ws[q] ? (double)we[q] / ws[q] : 0.0, (unsigned long long)wruns[q]);
+        uint64_t b1 = 0, b10 = 0, ball = 0;
+        for (uint32_t i = 0; i < pb->nbins; i++) { ball += bs[border[i]]; if (i < (pb->nbins + 99) / 100) b1 += bs[border[i]]; if (i < (pb->nbins + 9) / 10) b10 += bs[border[i]]; }
+        fprintf(stderr, "[pb] row bins: %u; the heaviest 1 %% hold %.1f %% of the slots, the heaviest 10 %% %.1f %% (rows are in natural order: every bin mixes hub and tail rows)\n",
+                pb->nbins, 100.0 * b1 / std::max<uint64_t>(ball, 1), 100.0 * b10 / std::max<uint64_t>(ball, 1));
+    }
     k_scatter_u32<<<grid_for(nrun), TPB, 0, s>>>(order.as<uint32_t>(), kscan.as<uint32_t>(), nrun, pkstart.as<uint32_t>());
     DevBuf binoff; PB_ALLOC(binoff, (uint64_t)(pb->nbins + 1) * 4);
     k_bin_offsets<<<grid_for(pb->nbins + 1), TPB, 0, s>>>(runbin_s.as<uint32_t>(), kscan.as<uint32_t>(), nrun, nout, pb->nbins, binoff.as<uint32_t>());

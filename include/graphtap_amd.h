@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 2 /* 2: gt_exec_stats grew (round 2: five fields; round 3: allocs_in_execute), gt_dist_* and gt_spmv_cf added */
+#define GT_ABI_VERSION 3 /* 2: gt_exec_stats grew (round 2: five fields; round 3: allocs_in_execute), gt_dist_* and gt_spmv_cf added; 3 (round 4): GT_ERR_TIMEOUT, gt_diag_hbm_ceiling */
 #define GT_INF 2147483647u /* apps/bfs.h:12 */
 
 typedef enum gt_status {
@@ -388,6 +388,14 @@ int gt_memcpy_h2d(void *dev_dst, const void *host_src, uint64_t bytes);
 int gt_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes);
 int gt_memset(void *dev_ptr, int value, uint64_t bytes);
 int gt_device_synchronize(void);
+
+/* ---- diagnostics ------------------------------------------------------- */
+/* This box's HBM streaming rate for one access mix, in GB/s, measured now (graphtap_amd/csrc/diag.hip; persistent grid, 16 B per
+ * lane, contiguous span per workgroup, best of three launches over two buffers of `bytes` bytes each, 64 MiB..32 GiB):
+ * mode 0 read only (non-temporal loads), 1 write only, 2 copy 1:1, 3 mix of 3 reads : 2 writes (phase 1 of the SpMV),
+ * 4 mix 16:1 with nt loads (phase 2 with the lean applicator), 5 mix 7:1 with nt loads (phase 2, full applicator).
+ * bench.py reports them beside roofline.achieved; no counterpart in the reference (it has no device). */
+int gt_diag_hbm_ceiling(int mode, uint64_t bytes, double *gbps);
 
 #ifdef __cplusplus
 }

@@ -17,11 +17,20 @@ VAL + LROW): 2 x FETCH matches them within 3 %. WRITE_SIZE is taken as is.
 """
 import collections
 import csv
+import datetime
 import glob
+import hashlib
 import json
 import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the SpMV kernels' source: bench.py reports `traffic` only while it still matches."""
+    return hashlib.sha256(open(os.path.join(ROOT, "graphtap_amd", "csrc", "pb.hip"), "rb").read()).hexdigest()[:16]
 
 
 def per_kernel(d, counter):
@@ -42,7 +51,9 @@ def main():
     rec = {"kernels": {k: {"hbm_read_bytes": 2 * fetch[k], "hbm_write_bytes": write.get(k, 0.0)} for k in sorted(fetch)
                        if k.startswith(("k_pb_", "k_spmv_edge", "k_pr_", "k_msg_", "k_apply_"))},
            "hbm_bytes_per_launch": sum(2 * fetch[k] + write.get(k, 0.0) for k in spmv),
-           "note": "one SpMV launch = k_pb_scatter_sparse + k_pb_scatter + k_pb_gather; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes"}
+           "note": "one SpMV launch = k_pb_scatter + k_pb_gather; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> bytes",
+           "collected": {"date": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"), "pb_hip_sha16": kernel_source_sha(),
+                         "commit": os.environ.get("GRAPHTAP_COMMIT", "unknown (the GPU box has no .git; set GRAPHTAP_COMMIT)")}}
     out = out_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     allrec = json.load(open(out)) if os.path.exists(out) else {}
     allrec[key] = rec

@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "missing export " + name
     assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
-    assert _lib.lib().gt_abi_version() == 2
+    assert _lib.lib().gt_abi_version() == 3
 
 
 def test_struct_layouts_match_header(tmp_path):

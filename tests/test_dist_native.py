@@ -306,6 +306,51 @@ def test_distributed_build_equals_the_replicated_build(gt, name, app, nranks, sl
         for d in dists: L.gt_dist_free(d)
 
 
+@pytest.mark.parametrize("nranks,bad_rank", [(2, 1), (3, 0), (8, 5)])
+def test_distributed_build_with_a_bad_record_on_one_rank_fails_on_every_rank_together(gt, nranks, bad_rank, monkeypatch):
+    """One out-of-range vertex id in ONE rank's share (the reference overflows its tile grid silently, matrix.hpp:218-220; this
+    library rejects the input): after the shuffle only the record's new holder sees it. Every rank must return an error from
+    gt_graph_build_distributed -- none may stay behind in the collectives that follow -- and quickly (the status word is summed
+    before every collective stage, ingest.hip: ing_agree), not at the deadline. The ranks then build a good graph on the same
+    communicator: it is still usable."""
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", "2")
+    monkeypatch.setenv("GRAPHTAP_TIMEOUT_S", "60")
+    c = load_case("rmat12"); nv = c["num_vertices"]
+    e = c["edges"]
+    flags = (True, True, True, False, True)
+    hs = (C.c_void_p * nranks)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, nranks))
+    dists = [C.c_void_p(hs[r]) for r in range(nranks)]
+
+    def run(shares):
+        Gs, errs = [None] * nranks, [None] * nranks
+
+        def build(r):
+            try:
+                L.gt_set_device(0)
+                G = gt.Graph(); G.load_share(dists[r], r, nranks, shares[r], nv, nv, *flags, gt._2DT_, gt._TCSC_CF_)
+                Gs[r] = G
+            except Exception as ex:   # noqa: BLE001
+                errs[r] = str(ex)
+        ts = [threading.Thread(target=build, args=(r,)) for r in range(nranks)]
+        for t in ts: t.start()
+        for t in ts: t.join(timeout=45)
+        assert not any(t.is_alive() for t in ts), "a rank is still inside the build: its peers left it in a collective"
+        return Gs, errs
+    good = [e[r::nranks] for r in range(nranks)]
+    bad = [np.array(x, copy=True) for x in good]
+    bad[bad_rank][len(bad[bad_rank]) // 2, 1] = nv + 12345          # one record names a vertex that does not exist
+    Gs, errs = run(bad)
+    assert all(G is None for G in Gs) and all(errs), errs
+    assert sum("vertex id > num_vertices" in x for x in errs) >= 1, errs          # the holder's own message
+    assert sum("failed while" in x for x in errs) == nranks - sum("vertex id > num_vertices" in x for x in errs), errs
+    Gs, errs = run(good)
+    assert not any(errs), errs
+    for G in Gs: G.free()
+    for d in dists: L.gt_dist_free(d)
+
+
 def test_mismatched_exchange_plans_are_reported_not_hung(gt, monkeypatch):
     """Two ranks whose graphs were built from different edge lists: the first execute compares every rank's send counts with
     every receiver's recv counts (plan_verify) and every rank returns an error -- the grouped send/recv rounds would hang."""

@@ -1021,6 +1021,33 @@ def test_api_misuse_is_reported_not_fatal(gt):
     VR.free(); V.free(); G.free()
 
 
+def test_every_wait_of_execute_has_a_deadline(gt, monkeypatch):
+    """gt_program_execute never spins for ever: with a deadline far shorter than the run (GRAPHTAP_TIMEOUT_S, read at every
+    wait) the call returns GT_ERR_TIMEOUT with a message -- never a hang with a core at 100 %, never a re-exec -- for the
+    fixed-count loop (the wait at the end of execute()) and for converge mode (the per-iteration read-back, gt_read_back).
+    The device is drained afterwards and the same handles run again to the right answer with the default deadline."""
+    from graphtap_amd.rmat import rmat_edges
+    L = gt._lib.lib()
+    scale, nv = 20, 1 << 20
+    e = rmat_edges(scale, 16, 3)
+    G = gt.Graph(); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V)
+    monkeypatch.setenv("GRAPHTAP_TIMEOUT_S", "1e-7")
+    with pytest.raises(gt.GraphTapError, match="did not complete within"):
+        P.execute(400)                       # ~20 ms of queued kernels against a 0.1-us deadline
+    gt._lib.check(L.gt_device_synchronize())
+    with pytest.raises(gt.GraphTapError, match="did not complete within"):
+        P.initialize(V); P.execute()         # converge mode: the first read-back of the active count
+    gt._lib.check(L.gt_device_synchronize())
+    monkeypatch.delenv("GRAPHTAP_TIMEOUT_S")
+    P.initialize(V); P.execute(20)
+    got = P.V["rank"].copy()
+    P2 = gt.PR_Program(G, True, False, False, gt._ROW_); P2.initialize(V); P2.execute(20)
+    assert (np.abs(got - P2.V["rank"]) / P2.V["rank"]).max() < 1e-12
+    P2.free(); P.free(); V.free(); G.free()
+
+
 def test_multirank_tile_rows_are_balanced(gt):
     """Contiguous id ranges of R-MAT are badly skewed (tile-row 0 of 8 would hold ~44 % of the entries); the hashed
     internal id space must give every rank a similar share of entries, rows and columns."""

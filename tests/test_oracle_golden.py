@@ -9,6 +9,8 @@ PageRank must match the np=1 run bit for bit in fp64 (same summation order)
 and the np>1 runs to 1e-6 relative (the reference itself re-associates the
 sums across tiles there).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -170,3 +172,19 @@ def test_tcsc_cf_spmv_adds_up_to_the_plain_spmv(name):
     src = ~np.isin(g.IR, g.JC)
     part = g.spmv_cf_plus_f64(x, np.zeros(g.nnzrows), first=True, running=True, last=False)
     assert (part[~src] == want[~src]).all() and (part[src] == 0).all()
+
+
+def test_host_pagerank_step_model_is_pinned_to_the_oracle():
+    """tests/host_models.pagerank_step_from_records -- what the full-size GPU test recomputes iteration 20 of the headline
+    configuration with, from the raw record stream -- equals the oracle's iteration (itself bit-identical to the reference's
+    vectors above): rank_20 from rank_19 and the degrees, on the bundled sample and on a seeded R-MAT, records in ragged slices."""
+    from host_models import pagerank_step_from_records
+    from graphtap_amd.rmat import rmat_edges
+    cases = [(np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rmat10_1024.bin"), dtype="<u4").reshape(-1, 2), 1024), (rmat_edges(12, 16, 5), 1 << 12)]
+    for e, nv in cases:
+        r19 = O.run_app("pr", e, nv, iters=19); r20 = O.run_app("pr", e, nv, iters=20)
+        cut = len(e) // 3 + 1
+        got = pagerank_step_from_records([e[:cut], e[cut:2 * cut + 5], e[2 * cut + 5:]], r19["rank"], r19["degree"])
+        rel = np.abs(got - r20["rank"]) / r20["rank"]
+        assert rel.max() < 1e-13, rel.max()
+        r19["graph"].close(); r20["graph"].close()
