@@ -239,12 +239,14 @@ struct LoopCtx {
     uint64_t generation = 0;
     std::vector<LoopPeer> peer;
     bool aborted = false;   // a rank left gt_dist_execute with an error: nobody waits for it any more
-    bool barrier() {   // false: a peer failed, the caller gives up too
+    bool barrier() {   // false: a peer failed -- or never came (deadline, GRAPHTAP_TIMEOUT_S) -- and the caller gives up too
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
         const uint64_t gen = generation;
         if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen || aborted; });
+        else if (!cv.wait_for(lk, std::chrono::duration<double>(gt_wait_limit_s()), [&] { return generation != gen || aborted; })) {
+            aborted = true; arrived = 0; generation++; cv.notify_all();   // ranks that disagree on the shape of the loop must not wait for each other for ever
+        }
         return !aborted;
     }
     void abort() { std::unique_lock<std::mutex> lk(mu); aborted = true; arrived = 0; generation++; cv.notify_all(); }
@@ -305,13 +307,14 @@ namespace {
 // ---- per-iteration timing (HIP events; gt_dist_iteration_times)
 constexpr uint32_t GT_DIST_TIMED_ITERS = 64, GT_DIST_TIME_FIELDS = 7, GT_DIST_TICKS = 6;
 enum { T_START = 0, T_SEND_READY = 1, T_SPMV_DONE = 2, T_APPLY_DONE = 3, T_FIRST_SLICE = 4, T_LAST_SLICE = 5 };
-int tick(gt_dist *d, int which, hipStream_t s) {
-    if (!d->timing || d->t_iter >= GT_DIST_TIMED_ITERS) return GT_OK;
-    const size_t i = (size_t)d->t_iter * GT_DIST_TICKS + which;
+int tick_at(gt_dist *d, uint32_t it, int which, hipStream_t s) {
+    if (!d->timing || it >= GT_DIST_TIMED_ITERS) return GT_OK;
+    const size_t i = (size_t)it * GT_DIST_TICKS + which;
     while (d->tev.size() <= i) { hipEvent_t e; GT_HIP(hipEventCreate(&e)); d->tev.push_back(e); }
     GT_HIP(hipEventRecord(d->tev[i], s));
     return GT_OK;
 }
+int tick(gt_dist *d, int which, hipStream_t s) { return tick_at(d, d->t_iter, which, s); }
 // after the run: [pack, first slice in, last slice in, SpMV (send ready -> accumulators complete, exchange waits inside), apply,
 // rest of the iteration (next messages, all-reduce, host round trip), mode]; -1 = not measured
 int collect_times(gt_dist *d, uint32_t iterations, bool comm_ticks) {
@@ -567,14 +570,15 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = fa
     GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_ready, 0));   // sends read what scatter_gather packed; receives overwrite an x nobody reads any more
     while (d->ev_slice.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_slice.push_back(e); }
     while (d->ev_pack.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_pack.push_back(e); }
-    if (p->pack_deferred)   // slice by slice: the sends of slice k start when ITS packing is done (k_pack_send of a tile-row of 8 is 0.07 ms)
-        for (uint32_t k = 0; k < K; k++) { int st = gt_program_pack_slice(p, k); if (st != GT_OK) return st; GT_HIP(hipEventRecord(d->ev_pack[k], s)); }
+    // slice by slice, ON THE COMMUNICATION STREAM (round 4; on the compute stream until round 3): the sends of slice k follow ITS
+    // packing, and the compute stream -- which has nothing to do with the send buffer -- goes straight on to wait for slice 0
+    // (k_pack_send of a tile-row of 8 is 0.05 ms, 0.026 of it used to sit in front of the first send AND of phase 1)
     // one_round: every slice in ONE grouped round (a list iteration consumes all of them at once, and its messages are a few
     // pairs: K rounds of ~25 us each were most of its exchange)
     if (one_round) GT_NCCL(rccl()->GroupStart());
     for (uint32_t k = 0; k < K; k++) {
         uint64_t so = g->send_off[k], ro = g->recv_off[k];
-        if (p->pack_deferred) GT_HIP(hipStreamWaitEvent(d->comm_stream, d->ev_pack[k], 0));
+        if (p->pack_deferred) { int st = gt_program_pack_slice_on(p, k, d->comm_stream); if (st != GT_OK) return st; }
         if (!one_round) GT_NCCL(rccl()->GroupStart());
         for (uint32_t q = 0; q < P; q++) {
             const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
@@ -598,6 +602,56 @@ int exchange_issue(gt_dist *d, gt_program *p, hipStream_t s, bool one_round = fa
         int st = tick(d, T_FIRST_SLICE, d->comm_stream); if (st != GT_OK) return st;
         st = tick(d, T_LAST_SLICE, d->comm_stream); if (st != GT_OK) return st;
     }
+    return GT_OK;
+}
+// ONE slice of a dense exchange (stationary programs), issued as soon as ITS messages are final: the pipelined PageRank loop
+// calls it after part k of phase 2 (gt_program_phase2_part), so that slice k is packed and travels while the later parts -- and
+// then the receiver's phase 1 of the earlier slices -- run. `it` = the iteration that will consume the slice (for the
+// diagnostics). RCCL: the packing kernel itself runs on the communication stream, off the compute stream's critical path.
+int exchange_issue_slice(gt_dist *d, gt_program *p, hipStream_t s, uint32_t k, uint32_t it, hipEvent_t ready = nullptr) {
+    const gt_graph *g = p->g;
+    const uint32_t K = g->info.x_slices, P = g->info.nranks, w = p->x_bytes;
+    if (k == 0) d->exchanges++;
+    uint64_t so = g->send_off[k], ro = g->recv_off[k];
+    for (uint32_t q = 0; q < P; q++) { const uint64_t b = (uint64_t)g->send_counts[(size_t)k * P + q] * w; d->bytes_dense += b; d->bytes_sent += b; }
+    if (d->loop) {
+        LoopCtx &c = *d->loop;
+        int st = gt_program_pack_slice(p, k); if (st != GT_OK) return st;
+        GT_HIP(hipStreamSynchronize(s));                      // slice k of my send buffer is packed
+        GT_LOOP_BARRIER(c);
+        uint64_t dst = ro;
+        for (uint32_t src = 0; src < P; src++) {
+            const gt_graph *gs = c.peer[src].g;
+            uint64_t off = gs->send_off[k];
+            for (uint32_t q = 0; q < (uint32_t)d->rank; q++) off += gs->send_counts[(size_t)k * P + q];
+            const uint32_t n = g->recv_counts[(size_t)k * P + src];
+            GT_REQUIRE(n == gs->send_counts[(size_t)k * P + d->rank], GT_ERR_STATE, "exchange plan mismatch between ranks %u and %d (slice %u)", src, d->rank, k);
+            if (n) GT_HIP(hipMemcpyAsync((char *)p->x + dst * w, c.peer[src].send + off * w, (uint64_t)n * w, hipMemcpyDeviceToDevice, s));
+            dst += n;
+        }
+        GT_HIP(hipStreamSynchronize(s));
+        GT_LOOP_BARRIER(c);                                   // every rank has read slice k of every send buffer
+        return GT_OK;
+    }
+    const ncclDataType_t ty = (w == 8) ? ncclUint64 : ncclUint32;
+    while (d->ev_slice.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_slice.push_back(e); }
+    while (d->ev_pack.size() < K) { hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); d->ev_pack.push_back(e); }
+    // `ready`: the messages of slice k are final and nobody reads slice k of x any more (the event behind part k of phase 2, or -- the
+    // first exchange of a run -- the point the compute stream has reached)
+    if (!ready) { GT_HIP(hipEventRecord(d->ev_pack[k], s)); ready = d->ev_pack[k]; }
+    GT_HIP(hipStreamWaitEvent(d->comm_stream, ready, 0));
+    { int st = gt_program_pack_slice_on(p, k, d->comm_stream); if (st != GT_OK) return st; }
+    GT_NCCL(rccl()->GroupStart());
+    for (uint32_t q = 0; q < P; q++) {
+        const uint32_t ns = g->send_counts[(size_t)k * P + q], nr = g->recv_counts[(size_t)k * P + q];
+        if (ns) GT_NCCL(rccl()->Send((const char *)p->send + so * w, ns, ty, (int)q, d->comm, d->comm_stream));
+        if (nr) GT_NCCL(rccl()->Recv((char *)p->x + ro * w, nr, ty, (int)q, d->comm, d->comm_stream));
+        so += ns; ro += nr;
+    }
+    GT_NCCL(rccl()->GroupEnd());
+    GT_HIP(hipEventRecord(d->ev_slice[k], d->comm_stream));
+    if (k == 0) { int st = tick_at(d, it, T_FIRST_SLICE, d->comm_stream); if (st != GT_OK) return st; }
+    if (k + 1 == K) { int st = tick_at(d, it, T_LAST_SLICE, d->comm_stream); if (st != GT_OK) return st; }
     return GT_OK;
 }
 int exchange_consume(gt_dist *d, gt_program *p, uint32_t k, hipStream_t s) {
@@ -800,6 +854,47 @@ int lists_execute(gt_dist *d, gt_program *p, gt_exec_stats *stats, std::chrono::
     return GT_OK;
 }
 
+// ---- the pipelined loop of a fixed-count PageRank (stationary, K > 1 slices, fused applicator)
+// Per iteration: phase 1 of slice k as soon as slice k has landed (as before); then phase 2 in K parts, and after part k -- whose
+// fused applicator writes the messages of the columns that travel in slice k -- slice k of the NEXT iteration's exchange is packed
+// (on the communication stream) and sent, while the compute stream goes on with part k+1. The exchange no longer waits for the
+// whole applicator (dist.hip of round 3: ev_ready after apply), the packing leaves the compute stream altogether, and the first
+// slice has the rest of phase 2 to travel in. A peer posts its receive for slice k only after ITS part k, i.e. after all of its
+// phase 1 has read the previous x: nothing is overwritten early. (Replaces the bcast of every segment after its whole apply,
+// vp:843-862, 1083-1111.)
+int pipelined_execute(gt_dist *d, gt_program *p, uint32_t iters) {
+    const gt_graph *g = p->g;
+    const uint32_t K = g->info.x_slices;
+    hipStream_t s = p->stream;
+    // the K parts of phase 2 run one after the other on the compute stream; GRAPHTAP_P2_PARTS=2: side by side on streams of their own
+    const bool concurrent = !d->loop && getenv("GRAPHTAP_P2_PARTS") && atoi(getenv("GRAPHTAP_P2_PARTS")) == 2;   // (measured slower: engine.hip, gt_program_parts_begin)
+    d->sparse_now = false;     // (dense blocks only; a min program's last execute on this communicator may have left it set)
+    int st = tick(d, T_START, s); if (st != GT_OK) return st;
+    p->pack_deferred = true;   // scatter_gather writes the messages of the owned columns; the slices are packed where they are sent
+    st = gt_program_scatter_gather(p); if (st != GT_OK) return st;
+    for (uint32_t k = 0; k < K; k++) { st = exchange_issue_slice(d, p, s, k, 0); if (st != GT_OK) return st; }
+    for (bool first = true;; first = false) {
+        if (!first) { st = tick(d, T_START, s); if (st != GT_OK) return st; }
+        st = gt_program_fuse_apply(p, iters, 0); if (st != GT_OK) return st;
+        p->pr_state = gt_pr_state_mode(p, iters, false);
+        GT_REQUIRE(gt_program_parts_begin(p), GT_ERR_STATE, "pipelined loop: the fused applicator is not available any more");
+        st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;
+        for (uint32_t k = 0; k < K; k++) {
+            st = exchange_consume(d, p, k, s); if (st != GT_OK) return st;
+            st = gt_program_combine_slice(p, k); if (st != GT_OK) return st;   // phase 1 of slice k (helper streams); phase 2 is left out
+        }
+        const bool more = p->iteration + 1 < iters;
+        for (uint32_t k = 0; k < K; k++) {
+            st = gt_program_phase2_part(p, k, iters, concurrent ? 1 : 0); if (st != GT_OK) return st;
+            if (k + 1 == K) { st = tick(d, T_SPMV_DONE, s); if (st != GT_OK) return st; st = tick(d, T_APPLY_DONE, s); if (st != GT_OK) return st; }
+            if (more) { st = exchange_issue_slice(d, p, s, k, d->t_iter + 1, concurrent ? p->part_done[k] : nullptr); if (st != GT_OK) return st; }
+        }
+        d->t_iter++;
+        if (!more) break;
+    }
+    return GT_OK;
+}
+
 // Degree in _COL_ order: the column counts of all tile-rows are summed in the global column space
 int all_reduce_y(gt_dist *d, gt_program *p, hipStream_t s) {
     if (d->loop) {
@@ -847,12 +942,25 @@ int gt_dist_exchange_bytes(gt_dist *d, const void *send, const uint64_t *send_of
         GT_LOOP_BARRIER(c);
         return GT_OK;
     }
-    GT_NCCL(rccl()->GroupStart());
-    for (int q = 0; q < P; q++) {
-        if (send_bytes[q]) GT_NCCL(rccl()->Send((const char *)send + send_off[q], send_bytes[q], ncclUint8, q, d->comm, s));
-        if (recv_bytes[q]) GT_NCCL(rccl()->Recv((char *)recv + recv_off[q], recv_bytes[q], ncclUint8, q, d->comm, s));
+    // A rank's share for itself is a device copy. Between ranks: grouped rounds of at most 1 GiB per pair -- a single ncclSend of
+    // the 8.6 GB that R-MAT-26 at world size 1 hands to itself came back as garbage (found by bench.py going through the
+    // distributed build, round 4); chunk j of a pair is sent in the sender's round j and received in the receiver's round j, the
+    // pairs match in order whatever the number of rounds either side needs for its other peers.
+    GT_REQUIRE(send_bytes[d->rank] == recv_bytes[d->rank], GT_ERR_STATE, "exchange of the build: a rank's share for itself has two sizes");
+    if (send_bytes[d->rank]) GT_HIP(hipMemcpyAsync((char *)recv + recv_off[d->rank], (const char *)send + send_off[d->rank], send_bytes[d->rank], hipMemcpyDeviceToDevice, s));
+    const uint64_t CH = 1ull << 30;
+    uint64_t rounds = 0;
+    for (int q = 0; q < P; q++) if (q != d->rank) rounds = std::max(rounds, std::max((send_bytes[q] + CH - 1) / CH, (recv_bytes[q] + CH - 1) / CH));
+    for (uint64_t j = 0; j < rounds; j++) {
+        GT_NCCL(rccl()->GroupStart());
+        for (int q = 0; q < P; q++) {
+            if (q == d->rank) continue;
+            const uint64_t so = j * CH, ro = j * CH;
+            if (so < send_bytes[q]) GT_NCCL(rccl()->Send((const char *)send + send_off[q] + so, std::min(CH, send_bytes[q] - so), ncclUint8, q, d->comm, s));
+            if (ro < recv_bytes[q]) GT_NCCL(rccl()->Recv((char *)recv + recv_off[q] + ro, std::min(CH, recv_bytes[q] - ro), ncclUint8, q, d->comm, s));
+        }
+        GT_NCCL(rccl()->GroupEnd());
     }
-    GT_NCCL(rccl()->GroupEnd());
     return sync_deadline(d, s, "the record exchange of the distributed build");
 }
 // element-wise maximum over the ranks, in place (flags: a logical OR)
@@ -1020,10 +1128,21 @@ static int dist_execute_impl(gt_dist *d, gt_program *p, uint32_t iters, gt_exec_
     const char *penv = getenv("GRAPHTAP_DIST_PROTOCOL");   // "dense": the loop below for every program (A/B, tests)
     const char *sxenv = getenv("GRAPHTAP_SPARSE_EXCHANGE");   // "0": every block dense (the loop below)
     const bool lists = check && !col && !p->stationary && p->fl_enabled && !(penv && strcmp(penv, "dense") == 0) && !(sxenv && atoi(sxenv) == 0);
+    // A fixed-count PageRank on K > 1 slices runs PIPELINED: phase 2 part by part, slice k of the next iteration's exchange issued
+    // as soon as part k has written its messages (pipelined_execute). The decision is the same on every rank (program kind, K,
+    // environment); GRAPHTAP_P2_PARTS=0 keeps the loop below.
+    bool pipelined = false;
+    if (!lists && !check && !col && p->stationary && K > 1 && iters > 0 && p->iteration < iters && !p->converged) {
+        int st = gt_program_fuse_apply(p, iters, 0); if (st != GT_OK) return st;
+        pipelined = gt_program_parts_begin(p);
+        p->p2_by_parts = false;
+        if (!pipelined) { p->fuse_armed = false; p->cf_hint = false; }
+    }
     if (lists) { int st = lists_execute(d, p, stats, t0); if (st != GT_OK) { d->lists_protocol = false; d->sparse_now = false; return st; } }
+    else if (pipelined) { int st = pipelined_execute(d, p, iters); p->pack_deferred = false; p->p2_by_parts = false; if (st != GT_OK) return st; }
     else for (;;) {
         int st = tick(d, T_START, s); if (st != GT_OK) return st;
-        p->pack_deferred = !d->loop && !col && p->stationary && K > 1;   // stationary programs send dense blocks: packing and sending overlap slice by slice
+        p->pack_deferred = !d->loop && !col && p->stationary;   // stationary programs send dense blocks: every slice is packed on the communication stream, right in front of its sends
         st = gt_program_scatter_gather(p); if (st != GT_OK) { p->pack_deferred = false; return st; }
         if (!col) { st = gt_program_fuse_apply(p, iters, check ? 1 : 0); if (st != GT_OK) return st; p->pr_state = gt_pr_state_mode(p, iters, check); }
         st = tick(d, T_SEND_READY, s); if (st != GT_OK) return st;

@@ -568,6 +568,9 @@ int gt_program_free(gt_program *p) {
     for (hipEvent_t e : p->slice_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->slice_done) (void)hipEventDestroy(e);
     for (hipStream_t st : p->slice_streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : p->part_done) (void)hipEventDestroy(e);
+    for (hipStream_t st : p->part_streams) (void)hipStreamDestroy(st);
+    if (p->p2_go) (void)hipEventDestroy(p->p2_go);
     delete p;
     return GT_OK;
 }
@@ -876,16 +879,17 @@ int gt_program_scatter_gather(gt_program *p) {
     return GT_OK;
 }
 // the per-destination packing of slice k alone: the C++ driver sends slice k while slice k+1 is still being packed
-int gt_program_pack_slice(gt_program *p, uint32_t k) {
+int gt_program_pack_slice_on(gt_program *p, uint32_t k, hipStream_t s) {
     const gt_graph *g = p->g;
     if (!p->xseg || k >= g->info.x_slices) return GT_OK;
     const uint64_t lo = g->send_off[k], n = g->send_off[k + 1] - lo;
     if (!n) return GT_OK;
-    if (p->x_bytes == 8) k_pack_send<uint64_t><<<grid_for(n), TPB, 0, p->stream>>>((const uint64_t *)p->xseg, g->send_idx + lo, n, (uint64_t *)p->send + lo);
-    else k_pack_send<uint32_t><<<grid_for(n), TPB, 0, p->stream>>>((const uint32_t *)p->xseg, g->send_idx + lo, n, (uint32_t *)p->send + lo);
+    if (p->x_bytes == 8) k_pack_send<uint64_t><<<grid_for(n), TPB, 0, s>>>((const uint64_t *)p->xseg, g->send_idx + lo, n, (uint64_t *)p->send + lo);
+    else k_pack_send<uint32_t><<<grid_for(n), TPB, 0, s>>>((const uint32_t *)p->xseg, g->send_idx + lo, n, (uint32_t *)p->send + lo);
     GT_HIP(hipGetLastError());
     return GT_OK;
 }
+int gt_program_pack_slice(gt_program *p, uint32_t k) { return gt_program_pack_slice_on(p, k, p->stream); }
 
 // PageRank with apply armed to follow this combine (gt_program_execute, gt_program_fuse_apply): the epilogue phase 2 runs
 // for the row bins one workgroup owns. Returns false when nothing is to be fused.
@@ -896,6 +900,21 @@ static bool fused_epilogue(gt_program *p, gt_pr_epilogue *epi) {
     *epi = gt_pr_epilogue{p->rank_c, p->deg_c, p->C_c, gt_row_slot(g), p->xseg ? p->xseg : p->x, p->x_f32 ? 1 : 0, p->prm.alpha, p->prm.tol,
                           cf ? 1 : 0, (p->fuse_iters != 0 && p->iteration + 1 == p->fuse_iters) ? 1 : 0, p->fuse_count ? p->d_active : nullptr, p->pr_state};
     return true;
+}
+
+// the next event of the program's SpMV timing pairs
+static int gt_timing_event(gt_program *p, hipStream_t s, hipEvent_t *out) {
+    if (p->ev_used + 1 > p->ev.size()) {
+        // the pairs recorded so far are folded into a running sum and their events used again (a drain of the stream every
+        // 32 SpMVs; no event is created inside the iteration loop). Only at a pair boundary: a sliced SpMV holds one open.
+        if ((p->ev_used & 1) == 0) {
+            { int st = gt_stream_wait_deadline(s, "the iteration loop (timing events)"); if (st != GT_OK) return st; }
+            for (size_t i = 0; i + 1 < p->ev_used; i += 2) { float ms = 0; GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1])); p->ev_acc_ms += ms; p->ev_acc_pairs++; }
+            p->ev_used = 0;
+        } else { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
+    }
+    *out = p->ev[p->ev_used++];
+    return GT_OK;
 }
 
 // slices [lo, hi) of the K = x_slices steps of one SpMV; the accumulators are complete after hi == K
@@ -915,19 +934,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         if (p->stationary && !p->y_clean) GT_HIP(hipMemsetAsync(p->y, 0, p->y_elems * p->y_bytes, s));  // K13, vp:1026-1032
         p->y_clean = false;
     }
-    auto timing_event = [&](hipEvent_t *out) -> int {
-        if (p->ev_used + 1 > p->ev.size()) {
-            // the pairs recorded so far are folded into a running sum and their events used again (a drain of the stream every
-            // 32 SpMVs; no event is created inside the iteration loop). Only at a pair boundary: a sliced SpMV holds one open.
-            if ((p->ev_used & 1) == 0) {
-                { int st = gt_stream_wait_deadline(s, "the iteration loop (timing events)"); if (st != GT_OK) return st; }
-                for (size_t i = 0; i + 1 < p->ev_used; i += 2) { float ms = 0; GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1])); p->ev_acc_ms += ms; p->ev_acc_pairs++; }
-                p->ev_used = 0;
-            } else { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
-        }
-        *out = p->ev[p->ev_used++];
-        return GT_OK;
-    };
+    auto timing_event = [&](hipEvent_t *out) -> int { return gt_timing_event(p, s, out); };
     const bool sliced = K > 1 && !(lo == 0 && hi >= K);
     if (!sliced) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -996,6 +1003,7 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
         if (st != GT_OK) return st;
         GT_HIP(hipEventRecord(p->slice_done[k], hs));
     }
+    if (hi >= K && p->p2_by_parts) return GT_OK;   // the driver runs phase 2 part by part (gt_program_phase2_part)
     if (hi >= K) {
         for (uint32_t k = 0; k < K; k++) GT_HIP(hipStreamWaitEvent(s, p->slice_done[k], 0));
         gt_pr_epilogue epi{};
@@ -1017,6 +1025,85 @@ int gt_program_combine_slice(gt_program *p, uint32_t k) {
     GT_REQUIRE(k < p->g->info.x_slices, GT_ERR_INVALID, "slice %u of %u", k, p->g->info.x_slices);
     return combine_impl(p, p->timing, k, k + 1);
 }
+// ---- phase 2 PART BY PART (the pipelined multi-rank loop of a fixed-count PageRank, dist.hip). With K slices the phase-2 work
+// list has K parts (pb.hip, gt_pb::work_part): part k holds the row bins whose rows' columns travel in slice k of the NEXT
+// iteration's exchange. After part k -- its fused applicator, and the apply kernel over the split bins of the part -- the
+// messages of slice k are final: the driver packs and sends them while parts k+1.. still run, instead of waiting for the whole
+// applicator (the reference broadcasts a segment only after its whole apply, vp:843-862).
+// gt_program_parts_begin: after gt_program_fuse_apply, before the combine_slice calls of the iteration; false = not possible
+// for this program (the caller takes the ordinary loop).
+bool gt_program_parts_begin(gt_program *p) {
+    const gt_graph *g = p->g;
+    p->p2_by_parts = false;
+    // GRAPHTAP_P2_PARTS: 1 = on (parts one after the other on the compute stream), 2 = on, the parts side by side on streams of
+    // their own; unset / 0 = off. BUILT, MEASURED AND LEFT OFF (round 4, profiles/r04/ab_phase2_parts_*.txt): on a tile-row of 8
+    // of R-MAT-26 phase 2 is ONE round of workgroups (207 row bins on 256 CUs), so its duration is one workgroup's streaming
+    // time and every part repeats it: 0.303 -> 0.363 ms of compute per step with 2 parts, 0.332 -> 0.547 with 4 (side by side:
+    // 0.444 / 0.854); on the whole graph (1 821 workgroups, RCCL at world size 1, K = 4) the parts gave 2.09 -> 2.06 ms per step,
+    // but moving the packing kernel to the communication stream alone gave 2.09 -> 1.96 in the ordinary loop, against which the
+    // parts LOSE (2.04). The early slices buy less than the extra launches and the emptier chip cost.
+    const char *e = getenv("GRAPHTAP_P2_PARTS");
+    const int mode = e ? atoi(e) : 0;
+    if (mode <= 0 || p->converged || p->prm.kind != GT_PR || p->prm.order == GT_COL || !p->fuse_armed || p->fuse_count || !g->pb || g->spmv_variant == GT_SPMV_EDGE) return false;
+    // (nothing rank-local may enter this decision -- every rank of a run must take the same loop: a tile-row without entries has
+    // its K empty parts like any other, pb.hip; the tile height is the same on every rank)
+    if (g->info.x_slices < 2 || gt_pb_parts(g) != g->info.x_slices) return false;
+    p->p2_by_parts = true;
+    return true;
+}
+// `concurrent`: part k runs on a stream of its own (priority descending with k), all parts side by side -- a tile-row of 8 has
+// ~200 row bins for 256 CUs, so K launches one after the other would leave most of the chip idle in each; side by side the
+// workgroups of part 0 are dispatched first and part 0 completes when they do (about half way through phase 2), without
+// making phase 2 any longer. part_done[k] is recorded behind part k; the caller's stream joins them after the last part.
+int gt_program_phase2_part(gt_program *p, uint32_t k, uint32_t num_iterations, int concurrent) {
+    GT_REQUIRE(p && p->initialized && p->p2_by_parts, GT_ERR_STATE, "phase2_part without gt_program_parts_begin");
+    const gt_graph *g = p->g;
+    hipStream_t s = p->stream;
+    const uint32_t K = g->info.x_slices, nr = g->info.nnzrows;
+    GT_REQUIRE(k < K, GT_ERR_INVALID, "part %u of %u", k, K);
+    const bool cf = p->prm.compression == GT_TCSC_CF;
+    if (p->part_done.size() < K) {
+        int least = 0, greatest = 0;
+        GT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));   // numerically lower = higher priority
+        while (p->part_done.size() < K) {
+            hipEvent_t e; GT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->part_done.push_back(e);
+            hipStream_t t; const int pr = std::min(least, greatest + (int)p->part_streams.size());
+            GT_HIP(hipStreamCreateWithPriority(&t, hipStreamNonBlocking, pr)); p->part_streams.push_back(t);
+        }
+        GT_HIP(hipEventCreateWithFlags(&p->p2_go, hipEventDisableTiming));
+    }
+    if (k == 0) {
+        for (uint32_t i = 0; i < K; i++) GT_HIP(hipStreamWaitEvent(s, p->slice_done[i], 0));   // every phase-1 slice has written its value-stream slots
+        if (p->iteration == 0 && !cf) k_clear_empty_rows<<<grid_for(g->info.tile_height), TPB, 0, s>>>(p->C, g->IJ, g->info.tile_height);   // what apply() does first (vp:1641-1650)
+        if (concurrent) GT_HIP(hipEventRecord(p->p2_go, s));
+    }
+    hipStream_t ps = concurrent ? p->part_streams[k] : s;
+    if (concurrent) GT_HIP(hipStreamWaitEvent(ps, p->p2_go, 0));
+    gt_pr_epilogue epi{};
+    GT_REQUIRE(fused_epilogue(p, &epi), GT_ERR_STATE, "phase2_part: the fused applicator is not armed");
+    int st = gt_launch_spmv(g, p->semiring, p->x, p->y, ps, p->x_f32, p, p->init_epoch, K, K, GT_PB_PHASE2, &epi, false, p->f32_capable && !p->x_f32, k, k + 1);
+    if (st != GT_OK) return st;
+    uint32_t nlist = 0;
+    const uint32_t *list = gt_pb_split_bins_part(g, k, &nlist);   // the bins of this part that phase 2 did not apply itself
+    if (nlist) {
+        const int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
+        void *xm = p->xseg ? p->xseg : p->x;
+        const uint64_t nwork = (uint64_t)nlist << GT_PB_ROW_BIN_BITS;
+        if (p->x_f32) k_pr_apply_msg<float><<<grid_for(nwork), TPB, 0, ps>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm, p->prm.alpha, p->prm.tol, cf, last, nullptr, list, nlist, p->pr_state);
+        else k_pr_apply_msg<double><<<grid_for(nwork), TPB, 0, ps>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (double *)xm, p->prm.alpha, p->prm.tol, cf, last, nullptr, list, nlist, p->pr_state);
+    }
+    GT_HIP(hipGetLastError());
+    GT_HIP(hipEventRecord(p->part_done[k], ps));   // the messages of slice k are final
+    if (k + 1 == K) {   // the iteration is complete: what combine's end and apply() leave behind (apply_launch, apply_finish)
+        if (concurrent) for (uint32_t i = 0; i < K; i++) GT_HIP(hipStreamWaitEvent(s, p->part_done[i], 0));
+        if (p->timing) { hipEvent_t e1; st = gt_timing_event(p, s, &e1); if (st != GT_OK) return st; GT_HIP(hipEventRecord(e1, s)); p->spmv_done++; }
+        p->fused = false; p->fuse_armed = false; p->cf_hint = false; p->p2_by_parts = false;
+        p->v_stale = true; p->x_fresh = true; p->y_clean = true; p->pr_state = 0; p->last_active = ~0ull;
+        p->iteration++;   // vp:421
+    }
+    return GT_OK;
+}
+
 static bool fuse_enabled() {
     const char *e = getenv("GRAPHTAP_FUSE_APPLY");
     return !(e != nullptr && atoi(e) == 0);   // on by default

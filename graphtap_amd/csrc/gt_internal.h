@@ -220,6 +220,7 @@ struct gt_program {
     bool x_deferred = false, x_stale = false;
     bool rowless_reset = false;   // the messages of vertices without a row were reset once (first apply that wrote messages itself)
     bool pack_deferred = false;   // scatter_gather leaves the per-destination packing to gt_program_pack_slice (the C++ multi-rank driver)
+    bool p2_by_parts = false;     // this iteration's phase 2 runs part by part (gt_program_phase2_part): combine's last slice leaves it out
     // TCSC_CF computation filtering: the driver told us which iteration is the last (execute / gt_program_fuse_apply), so the
     // SpMVs before it may leave the source rows' entries out (vp:1264-1317)
     bool cf_hint = false;
@@ -234,6 +235,9 @@ struct gt_program {
     int pr_state = 0;
     std::vector<hipStream_t> slice_streams;
     std::vector<hipEvent_t> slice_in, slice_done;   // per slice: "inputs ready" (recorded on `stream`), "phase 1 done"
+    std::vector<hipStream_t> part_streams;          // phase 2 part by part: a stream per part, priority descending (gt_program_phase2_part)
+    std::vector<hipEvent_t> part_done;              // ... "part k and the apply of its split bins are done: the messages of slice k are final"
+    hipEvent_t p2_go = nullptr;                     // ... "phase 1 is complete" (recorded on `stream`)
 };
 
 #define GT_FRONTIER_CAP (1u << 24)   // longest frontier kept as a list
@@ -277,7 +281,9 @@ const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n);   // the bins 
 uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
-               const gt_pr_epilogue *epi = nullptr, bool skip_source = false);
+               const gt_pr_epilogue *epi = nullptr, bool skip_source = false, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu);
+uint32_t gt_pb_parts(const gt_graph *g);   // parts of the phase-2 work list (x_slices on a graph with an exchange layout, else 1; pb.hip, gt_pb::work_part)
+const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n);   // the split bins of part k
 int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s);   // allocates + touches VAL (initialize time)
 int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hipStream_t s);   // initialize() of BFS / SSSP / CC: VAL all infinity(), owned by that program
 uint32_t gt_pb_val_allocs(const gt_graph *g);   // how many times VAL was (re)allocated so far
@@ -344,6 +350,9 @@ int gt_tail_try(gt_program *p, hipStream_t s, bool *converged, uint32_t *iterati
 int gt_spmspv_run_frontier(gt_program *p, uint32_t nact, hipStream_t s);
 // apply() in two halves for a driver that reads the active count itself, together with other words (dist.hip)
 extern "C" int gt_program_pack_slice(gt_program *p, uint32_t k);
+extern "C" int gt_program_pack_slice_on(gt_program *p, uint32_t k, hipStream_t s);   // ... on a stream of the caller's (the communication stream: off the compute stream's critical path)
+extern "C" bool gt_program_parts_begin(gt_program *p);                               // phase 2 part by part (engine.hip): the pipelined multi-rank PageRank loop
+extern "C" int gt_program_phase2_part(gt_program *p, uint32_t k, uint32_t num_iterations, int concurrent);
 extern "C" int gt_program_apply_begin(gt_program *p, uint32_t num_iterations);
 extern "C" int gt_program_apply_end(gt_program *p, uint64_t active_local);
 int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s);
@@ -351,4 +360,5 @@ int gt_launch_spmv_edge(const gt_graph *g, int semiring, const void *x, void *y,
 // min programs skip chunks without an active column (activity filtering)
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32 = false,
                    const void *owner = nullptr, uint64_t epoch = 0, uint32_t slice_lo = 0, uint32_t slice_hi = 0xFFFFFFFFu,
-                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr, bool skip_source = false, bool f64_messages = false);
+                   unsigned phases = 0, const gt_pr_epilogue *epi = nullptr, bool skip_source = false, bool f64_messages = false,
+                   uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu);

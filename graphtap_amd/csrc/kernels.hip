@@ -68,16 +68,17 @@ __global__ void __launch_bounds__(TPB) k_spmv_edge(const uint32_t *__restrict__ 
 }  // namespace
 
 int gt_launch_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool x_is_f32, const void *owner, uint64_t epoch,
-                   uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source, bool f64_messages) {
+                   uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source, bool f64_messages,
+                   uint32_t part_lo, uint32_t part_hi) {
     const uint32_t K = g->info.x_slices;
     if (slice_hi > K) slice_hi = K;
     if (g->spmv_variant == GT_SPMV_PB_F32MSG && f64_messages) {   // a converge-mode PageRank on a graph whose default is f32 messages (gt_program_prepare)
         GT_REQUIRE(!x_is_f32, GT_ERR_STATE, "f64 messages were asked for with an f32 message vector");
-        return gt_pb_spmv(g, semiring, x, y, s, false, false, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source);
+        return gt_pb_spmv(g, semiring, x, y, s, false, false, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
     }
-    if (g->spmv_variant == GT_SPMV_PB_F32MSG) return gt_pb_spmv(g, semiring, x, y, s, true, x_is_f32, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source);
+    if (g->spmv_variant == GT_SPMV_PB_F32MSG) return gt_pb_spmv(g, semiring, x, y, s, true, x_is_f32, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
     GT_REQUIRE(!x_is_f32, GT_ERR_STATE, "this program was created for GT_SPMV_PB_F32MSG (f32 message vector); select the SpMV variant before creating programs");
-    if (g->spmv_variant == GT_SPMV_PB) return gt_pb_spmv(g, semiring, x, y, s, false, false, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source);
+    if (g->spmv_variant == GT_SPMV_PB) return gt_pb_spmv(g, semiring, x, y, s, false, false, owner, epoch, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
     GT_REQUIRE(epi == nullptr, GT_ERR_STATE, "the fused PageRank epilogue needs a propagation-blocking SpMV variant");
     if (phases ? !(phases & GT_PB_PHASE2) : slice_hi < K) return GT_OK;   // the edge kernel is not sliced: everything happens with the last stage
     return gt_launch_spmv_edge(g, semiring, x, y, s);

@@ -920,6 +920,12 @@ struct gt_pb {
     uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
     uint32_t *split_bins = nullptr;     // [nsplit] the other bins (with entries): their rows go through y and the apply kernel
     uint32_t nsplit = 0;
+    // Exchange layout, K slices: the phase-2 work list in K PARTS -- part k = the row bins whose first row's column travels in
+    // slice k of the NEXT iteration's exchange (rows and the columns of the same vertices ascend together, the slice of compressed
+    // column j is j / slice_width) -- so that the messages of slice k are complete, packed and on the wire while parts k+1..
+    // still run (gt_program_phase2_part, dist.hip). work[work_part[k] .. work_part[k+1]) (largest first inside a part),
+    // split_bins[split_part[k] .. split_part[k+1]).
+    std::vector<uint32_t> work_part, split_part;
     uint32_t rows_single = 0;           // rows of those bins
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
@@ -1037,7 +1043,11 @@ int gt_pb_build(gt_graph *g) {
     pb->nnz = nnz;
     pb->nbins = std::max<uint32_t>(1, (nr + R - 1) / R);
     g->pb = nullptr;
-    if (nnz == 0) { g->pb = pb; return GT_OK; }
+    if (nnz == 0) {   // a tile-row without entries: nothing to stream, but the K (empty) parts of phase 2 exist like everywhere else
+        const uint32_t KP = gt_has_exchange(g) ? std::max<uint32_t>(g->info.x_slices, 1) : 1;
+        pb->work_part.assign(KP + 1, 0); pb->split_part.assign(KP + 1, 0);
+        g->pb = pb; return GT_OK;
+    }
     hipStream_t s = 0;
     int binbits = 1;
     while ((1u << binbits) < pb->nbins) binbits++;
@@ -1336,6 +1346,34 @@ int gt_pb_build(gt_graph *g) {
     // heavy (hub) bins must not end up in the last of the ~7 rounds
     if (!getenv("GRAPHTAP_PB_BIN_ORDER"))
         std::stable_sort(work.begin(), work.end(), [](const BinWork &a, const BinWork &b) { return a.k1 - a.k0 > b.k1 - b.k0; });
+    {   // parts of the work list (see gt_pb::work_part): one part on graphs without slices
+        const uint32_t KP = gt_has_exchange(g) ? std::max<uint32_t>(g->info.x_slices, 1) : 1;
+        std::vector<uint32_t> part_of_bin(pb->nbins, 0);
+        if (KP > 1 && nr) {
+            std::vector<uint32_t> r2c(nr);
+            PB_HIP(hipMemcpy(r2c.data(), g->R2C, (uint64_t)nr * 4, hipMemcpyDeviceToHost));
+            const uint32_t T = std::max<uint32_t>(g->info.slice_width, 1);
+            uint32_t last = 0;
+            for (uint32_t b = 0; b < pb->nbins; b++) {
+                uint32_t part = last;   // a bin of source rows only (no columns): with its predecessor
+                for (uint32_t r = b * R; r < std::min<uint64_t>((uint64_t)(b + 1) * R, nr); r++)
+                    if (r2c[r] != 0xFFFFFFFFu) { part = std::min(r2c[r] / T, KP - 1); break; }
+                part_of_bin[b] = last = std::max(part, last);   // monotone: slice k is complete once the parts <= k are
+            }
+        }
+        std::stable_sort(work.begin(), work.end(), [&](const BinWork &a, const BinWork &b) { return part_of_bin[a.bin] < part_of_bin[b.bin]; });
+        pb->work_part.assign(KP + 1, (uint32_t)work.size()); pb->split_part.assign(KP + 1, pb->nsplit);
+        pb->work_part[0] = 0; pb->split_part[0] = 0;
+        for (uint32_t k = 1; k < KP; k++) {
+            pb->work_part[k] = (uint32_t)(std::lower_bound(work.begin(), work.end(), k, [&](const BinWork &a, uint32_t kk) { return part_of_bin[a.bin] < kk; }) - work.begin());
+            uint32_t i = 0;
+            std::vector<uint32_t> hs(pb->nsplit);
+            if (pb->nsplit) PB_HIP(hipMemcpy(hs.data(), pb->split_bins, (uint64_t)pb->nsplit * 4, hipMemcpyDeviceToHost));
+            while (i < pb->nsplit && part_of_bin[hs[i]] < k) i++;   // (the split list ascends by bin, parts ascend with the bins)
+            pb->split_part[k] = i;
+        }
+        if (stats && KP > 1) { fprintf(stderr, "[pb] phase 2 in %u parts (workgroups):", KP); for (uint32_t k = 0; k < KP; k++) fprintf(stderr, " %u", pb->work_part[k + 1] - pb->work_part[k]); fprintf(stderr, "\n"); }
+    }
     PB_MALLOC(pb->work, work.size() * sizeof(BinWork));
     PB_HIP(hipMemcpy(pb->work, work.data(), work.size() * sizeof(BinWork), hipMemcpyHostToDevice));
     if (pb->nwork) k_work_chunks<<<grid_for(pb->nwork), TPB, 0, s>>>(pb->work, pb->nwork, kscan.as<uint32_t>(), order.as<uint32_t>(), runkey.as<uint32_t>(), nrun, binbits);
@@ -1371,7 +1409,7 @@ int gt_pb_build(gt_graph *g) {
 
 template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy = uint32_t>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
-                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source) {
+                  uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source, uint32_t part_lo, uint32_t part_hi) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see stage_window).
     const bool filter = IS_MIN && owner != nullptr && !getenv("GRAPHTAP_NO_ACTIVITY_FILTERING");
     if (phases & GT_PB_PREPARE) {
@@ -1405,15 +1443,22 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     if (phases & GT_PB_PHASE2) {
         if (filter) k_active_prefix<<<1, 1024, 0, s>>>(pb->chunk_active, pb->nchunks, pb->active_prefix);
         const uint32_t *ap = filter ? pb->active_prefix : nullptr;
-        if constexpr (std::is_same<T, double>::value) {
-            if (epi && epi->x_f32)
-                k_pb_gather<T, TV, IS_MIN, 1><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
-            else if (epi)
-                k_pb_gather<T, TV, IS_MIN, 2><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
-            else
-                k_pb_gather<T, TV, IS_MIN, 0><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
-        } else {
-            k_pb_gather<T, TV, IS_MIN, 0><<<pb->nwork, P2_THREADS, 0, s>>>(pb->work, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+        // the parts [part_lo, part_hi) of the work list (all of it by default; gt_pb::work_part)
+        const uint32_t np_ = (uint32_t)pb->work_part.size() - 1;
+        const uint32_t w0 = pb->work_part[std::min(part_lo, np_)], w1 = pb->work_part[std::min(part_hi, np_)];
+        const BinWork *wk = pb->work + w0;
+        const uint32_t nw = w1 - w0;
+        if (nw) {
+            if constexpr (std::is_same<T, double>::value) {
+                if (epi && epi->x_f32)
+                    k_pb_gather<T, TV, IS_MIN, 1><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+                else if (epi)
+                    k_pb_gather<T, TV, IS_MIN, 2><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+                else
+                    k_pb_gather<T, TV, IS_MIN, 0><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+            } else {
+                k_pb_gather<T, TV, IS_MIN, 0><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+            }
         }
     }
     if (pt) { GT_HIP(hipEventRecord(pb->pt_ev[pb->pt_used + 2], s)); pb->pt_used += 3; }
@@ -1462,6 +1507,13 @@ uint32_t gt_pb_val_allocs(const gt_graph *g) { return g->pb ? g->pb->val_allocs 
 
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
 const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n) { *n = g->pb ? g->pb->nsplit : 0; return g->pb ? g->pb->split_bins : nullptr; }
+uint32_t gt_pb_parts(const gt_graph *g) { return g->pb && !g->pb->work_part.empty() ? (uint32_t)g->pb->work_part.size() - 1 : 1; }
+const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n) {   // the split bins of part k of the phase-2 work list
+    *n = 0;
+    if (!g->pb || g->pb->split_part.size() < 2 || k + 1 >= g->pb->split_part.size()) return nullptr;
+    *n = g->pb->split_part[k + 1] - g->pb->split_part[k];
+    return g->pb->split_bins + g->pb->split_part[k];
+}
 uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
 uint64_t gt_pb_source_entries(const gt_graph *g) { return g->pb ? g->pb->nnz_source : 0; }
 
@@ -1478,7 +1530,8 @@ int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hi
 }
 
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
-               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source) {
+               const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source,
+               uint32_t part_lo, uint32_t part_hi) {
     gt_pb *pb = g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
@@ -1496,16 +1549,16 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
-            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
-            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
-            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source);
-        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr, false);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
+            if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
+            if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
+            return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
+        case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
-            if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
-            if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
-            return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false);
+            if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+            if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+            return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
         default: gt_set_error("unknown semiring %d", semiring); return GT_ERR_INVALID;
     }
 }

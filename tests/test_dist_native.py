@@ -151,6 +151,49 @@ def test_cpp_driver_over_loopback_reproduces_the_reference(gt, name, nranks, sli
         for d in dists: L.gt_dist_free(d)
 
 
+@pytest.mark.parametrize("nranks,slices,variant", [(2, 4, "pb_f32msg"), (3, 2, "pb"), (8, 2, "pb_f32msg")])
+@pytest.mark.parametrize("name", ["tiny", "rmat12"])
+def test_phase2_part_by_part_loop_gives_the_same_ranks(gt, name, nranks, slices, variant, monkeypatch):
+    """The pipelined loop of a fixed-count PageRank (GRAPHTAP_P2_PARTS=1; built and measured in round 4, off by default: it loses on
+    the tile-rows it was meant for, engine.hip gt_program_parts_begin): phase 2 in K parts, slice k of the next iteration's
+    exchange issued behind part k. Ranks against the reference's vectors and against the ordinary loop, runs continued by a
+    second execute, tile-rows without entries (8 ranks on the tiny graph) included."""
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_SPMV", variant)
+    monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices))
+    monkeypatch.setenv("GRAPHTAP_TIMEOUT_S", "60")
+    c = load_case(name); nv = c["num_vertices"]; n = nv + 1
+    hs = (C.c_void_p * nranks)()
+    gt._lib.check(L.gt_dist_create_loopback(hs, nranks))
+    dists = [C.c_void_p(hs[r]) for r in range(nranks)]
+    try:
+        Gs = []
+        for r in range(nranks):
+            G = gt.Graph(); G.load_edges(c["edges"], nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=r, nranks=nranks); Gs.append(G)
+        degs = [gt.Deg_Program(G, True, False, False, gt._COL_) for G in Gs]
+        for p in degs: p.initialize()
+        _dist_execute_all(gt, dists, degs, 1)
+        prs = [gt.PR_Program(G, True, False, False, gt._ROW_) for G in Gs]
+        out = {}
+        for parts in ("0", "1"):
+            monkeypatch.setenv("GRAPHTAP_P2_PARTS", parts)
+            for p, d in zip(prs, degs): p.initialize(d)
+            it, _ = _dist_execute_all(gt, dists, prs, 3)
+            assert it == 3
+            r3 = _gather(prs, "rank", n)
+            it, _ = _dist_execute_all(gt, dists, prs, 20)          # continued: 17 more
+            assert it == 20
+            out[parts] = (r3, _gather(prs, "rank", n))
+        ref3, ref20 = c["np1_pr3_c"], c["np1_pr20_c"]
+        for parts in out:
+            assert (np.abs(out[parts][0] - ref3) / ref3).max() < PR_RTOL and (np.abs(out[parts][1] - ref20) / ref20).max() < PR_RTOL
+        assert (np.abs(out["1"][1] - out["0"][1]) / out["0"][1]).max() < 1e-12
+        for p in prs + degs: p.free()
+        for G in Gs: G.free()
+    finally:
+        for d in dists: L.gt_dist_free(d)
+
+
 def _min_apps_over_loopback(gt, c, nranks, known_answers, name):
     """BFS, CC, SSSP of one case on `nranks` loopback ranks: labels and iteration counts against the reference's goldens;
     returns the summed list_iterations / spmspv_iterations the ranks reported."""

@@ -251,6 +251,70 @@ def test_rccl_self_exchange_runs_the_multi_gpu_driver_path(gt, nccl_world1, slic
         assert gcs[1] == rcs[1] and abs(int(gcs[0]) - int(rcs[0])) <= (1 if k.startswith("pr") else 0), (k, gcs, rcs)
 
 
+@pytest.mark.parametrize("slices", [2, 4])
+def test_phase2_parts_over_rccl_world1(gt, nccl_world1, slices, monkeypatch):
+    """GRAPHTAP_P2_PARTS = 1 / 2 (phase 2 part by part, one after the other / side by side on prioritized streams; slice k packed on
+    the communication stream and sent behind part k) over RCCL at world size 1: the same ranks as the ordinary loop, whose own
+    packing now also runs on the communication stream."""
+    from graphtap_amd import dist_native
+    from graphtap_amd.rmat import rmat_edges
+    scale, nv = 18, 1 << 18
+    e = rmat_edges(scale, 16, 7)
+    monkeypatch.setenv("GRAPHTAP_FORCE_EXCHANGE", "1"); monkeypatch.setenv("GRAPHTAP_X_SLICES", str(slices)); monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    dist_native.init()
+    try:
+        G = gt.Graph(); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+        V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+        P = gt.PR_Program(G, True, False, False, gt._ROW_)
+        out = {}
+        for parts in ("0", "1", "2"):
+            monkeypatch.setenv("GRAPHTAP_P2_PARTS", parts)
+            P.initialize(V); P.execute(20)
+            out[parts] = (P.V["rank"].copy(), P.iteration, P.checksum(out=None))
+        P.free(); V.free(); G.free()
+    finally:
+        dist_native.free()
+    for parts in ("1", "2"):
+        assert out[parts][1] == out["0"][1] == 20
+        assert (np.abs(out[parts][0] - out["0"][0]) / out["0"][0]).max() < 1e-12
+        assert out[parts][2] == out["0"][2]
+
+
+def test_distributed_build_of_the_headline_graph_over_rccl_equals_the_replicated_build(gt, nccl_world1, monkeypatch):
+    """gt_graph_build_distributed (Matrix::distribute, mat/matrix.hpp:693-810) at the size bench.py --gpus N uses it: the 2^30
+    records of R-MAT-26 handed over as ONE share at world size 1 over RCCL (forced exchange layout) -- 8.6 GB through the record
+    exchange, where a single ncclSend of that size once came back as garbage (round 4; the smaller loopback cases of
+    tests/test_dist_native.py cannot see that). The graph must be the replicated build's: same info, and a 3-iteration PageRank
+    through the C++ multi-rank driver with the reference checksum of the single-rank engine."""
+    from graphtap_amd import dist_native
+    L = gt._lib.lib()
+    scale, nv = 26, 1 << 26
+    monkeypatch.setenv("GRAPHTAP_FORCE_EXCHANGE", "1"); monkeypatch.setenv("GRAPHTAP_X_SLICES", "2"); monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    dist_native.init()
+    try:
+        out = []
+        for mode in ("distributed", "replicated"):
+            d, m = _device_rmat(gt, scale, 1)
+            G = gt.Graph()
+            if mode == "distributed":
+                G.load_share(dist_native.handle(), 0, 1, d.value, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, m_share=m)
+            else:
+                G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+            gt._lib.check(L.gt_free(d))
+            V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+            P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(3)
+            info = {f: getattr(G.info, f) for f, _ in G.info._fields_}
+            out.append((info, P.checksum(out=None), int(G.nnz_global), P.V["rank"].copy()))
+            P.free(); V.free(); G.free()
+    finally:
+        dist_native.free()
+    (ia, ca, na, ra), (ib, cb, nb, rb) = out
+    assert ia == ib, {k: (ia[k], ib[k]) for k in ia if ia[k] != ib[k]}
+    assert na == nb == 16 << scale
+    assert ca[1] == cb[1] and abs(int(ca[0]) - int(cb[0])) <= 1, (ca, cb)
+    assert (np.abs(ra - rb) / rb).max() < 1e-12
+
+
 def test_config5_standin_cc_on_symmetrised_powerlaw_graph(gt):
     """BASELINE.json configs[4] is CC on Twitter-2010 (41.6 M vertices, 1.47 G edges, graphtap1.slurm:49); the file is
     not on the box (no network), so the DECLARED stand-in is a symmetrised R-MAT with Twitter's edge
