@@ -968,6 +968,8 @@ static int combine_impl(gt_program *p, bool timed, uint32_t lo, uint32_t hi) {
             if (!last) p->cf_filtered++;
             st = gt_tcsc_cf_spmv(const_cast<gt_graph *>(g), (const double *)p->x, (double *)p->y, p->iteration == 0, true, last, s);
         } else {
+            static const bool act_report = getenv("GRAPHTAP_WINDOW_ACTIVITY") != nullptr;
+            if (act_report && !sparse_done && !p->stationary) { int st2 = gt_pb_window_activity_report(g, p->x, s, p->iteration); if (st2 != GT_OK) return st2; }
             st = sparse_done ? GT_OK : gt_launch_spmv(g, p->semiring, p->x, p->y, s, p->x_f32, p, p->init_epoch, lo, hi, 0, fuse ? &epi : nullptr, skip_source, p->f32_capable && !p->x_f32);
         }
         if (st != GT_OK) return st;

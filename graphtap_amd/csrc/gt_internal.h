@@ -282,6 +282,7 @@ uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
                const gt_pr_epilogue *epi = nullptr, bool skip_source = false, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu);
+int gt_pb_window_activity_report(const gt_graph *g, const void *x, hipStream_t s, uint32_t iteration);   // GRAPHTAP_WINDOW_ACTIVITY=1 (diagnostic)
 uint32_t gt_pb_parts(const gt_graph *g);   // parts of the phase-2 work list (x_slices on a graph with an exchange layout, else 1; pb.hip, gt_pb::work_part)
 const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n);   // the split bins of part k
 int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s);   // allocates + touches VAL (initialize time)

@@ -473,6 +473,125 @@ __global__ void k_active_prefix(const uint32_t *__restrict__ active, uint32_t nc
     }
 }
 
+// ---- window activity (min programs): how many stored entries the ACTIVE columns of every window hold
+__global__ void k_slot_degrees(const uint32_t *__restrict__ JA, const uint32_t *__restrict__ xcol, uint32_t x_len, uint32_t *__restrict__ xdeg) {
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < x_len; sl += gridDim.x * blockDim.x) {
+        const uint32_t c = xcol ? xcol[sl] : sl;
+        xdeg[sl] = c == 0xFFFFFFFFu ? 0u : JA[c + 1] - JA[c];
+    }
+}
+__global__ void k_win_total(const uint32_t *__restrict__ wcount, uint32_t nwin, uint32_t ncls, uint32_t *__restrict__ win_entries) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwin; q += gridDim.x * blockDim.x) {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < ncls; k++) n += wcount[k * nwin + q];
+        win_entries[q] = n;
+    }
+}
+// one pass over x: a wave's 64 slots lie in one window almost always -> one atomic per wave
+__global__ void __launch_bounds__(256) k_window_activity(const uint32_t *__restrict__ x, const uint32_t *__restrict__ xdeg, uint32_t x_len, WinGeom geom,
+                                                         unsigned long long *__restrict__ win_act) {
+    const uint32_t n64 = (x_len + 63) & ~63u;
+    for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < n64; sl += gridDim.x * blockDim.x) {
+        const bool in = sl < x_len;
+        unsigned long long d = (in && x[sl] != GT_INF) ? xdeg[sl] : 0u;
+        const uint32_t q = in ? win_of(geom, sl) : 0xFFFFFFFFu;
+        const uint32_t q0 = __builtin_amdgcn_readfirstlane(q);
+        if (__all(q == q0 || !in)) {
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+            if ((threadIdx.x & 63) == 0 && d && q0 != 0xFFFFFFFFu) atomicAdd(&win_act[q0], d);
+        } else if (d) atomicAdd(&win_act[q], d);
+    }
+}
+
+// HYBRID pass, step 1 -- one workgroup per CANDIDATE window (the few windows that hold at least 1/256 of all entries each: the hub
+// windows, where the saving is): stages the window's messages and per-slot entry counts, adds up the entries of the ACTIVE
+// columns, and decides on the spot: none -> mode 2; at most 1/F of the window's entries -> mode 1, and the active columns are
+// appended to the (column, message, entries) list of the column-driven kernels (one reservation per workgroup); else mode 0 (stream).
+// (The first version counted all windows in a pass over x, chose in a second kernel, listed in a third: ~0.25 ms of small launches
+// per pass, more than it saved -- profiles/r04/ab_hybrid_pass_first_version.txt.)
+__global__ void __launch_bounds__(1024) k_hybrid_windows(const uint32_t *__restrict__ cand, const uint32_t *__restrict__ x, const uint32_t *__restrict__ xcol,
+                                                         const uint32_t *__restrict__ xdeg, uint32_t x_len, WinGeom geom, const uint32_t *__restrict__ win_entries,
+                                                         unsigned long long F, uint8_t *__restrict__ win_mode, unsigned int *__restrict__ cursor, uint32_t cap,
+                                                         uint32_t *__restrict__ col, uint32_t *__restrict__ val, uint32_t *__restrict__ deg,
+                                                         unsigned long long *__restrict__ stat) {
+    constexpr int PER = (WS + 1023) / 1024;
+    __shared__ unsigned long long part[16];
+    __shared__ unsigned int wcnt[16];
+    __shared__ unsigned long long total_s;
+    __shared__ unsigned int base_s;
+    const uint32_t q = cand[blockIdx.x];
+    const uint32_t col0 = win_col0(geom, q), wlim = q < geom.ndw ? W : WS;
+    const uint32_t wn = x_len - col0 < wlim ? x_len - col0 : wlim;
+    uint32_t v[PER], d[PER];
+    unsigned long long mine = 0; unsigned int ncols = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t j = threadIdx.x + i * 1024;
+        v[i] = GT_INF; d[i] = 0;
+        if (j < wn) { v[i] = x[col0 + j]; d[i] = xdeg[col0 + j]; }
+        if (v[i] != GT_INF && d[i]) { mine += d[i]; ncols++; } else d[i] = 0;
+    }
+    unsigned long long m2 = mine;
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_down(m2, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; w++) t += part[w]; total_s = t; }
+    __syncthreads();
+    const unsigned long long total = total_s;
+    const uint8_t mode = total == 0 ? 2 : (total * F <= win_entries[q] ? 1 : 0);
+    if (threadIdx.x == 0) {
+        win_mode[q] = mode;
+        if (stat && mode == 1) { atomicAdd(&stat[1], total); atomicAdd(&stat[2], (unsigned long long)win_entries[q]); atomicAdd(&stat[3], 1ull); }
+        if (stat && blockIdx.x == 0) atomicAdd(&stat[0], 1ull);
+    }
+    if (mode != 1) return;
+    // the active columns of this window -> the list: exclusive scan of the per-thread counts (wave scan + wave totals)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int incl = ncols;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned int t = 0; for (int w = 0; w < 16; w++) { const unsigned int n = wcnt[w]; wcnt[w] = t; t += n; } base_s = t ? atomicAdd(cursor, t) : 0u; }
+    __syncthreads();
+    uint32_t o = base_s + wcnt[wave] + (incl - ncols);
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (d[i]) { const uint32_t sl = col0 + threadIdx.x + i * 1024; if (o < cap) { col[o] = xcol ? xcol[sl] : sl; val[o] = v[i]; deg[o] = d[i]; } o++; }
+}
+// eight lanes per listed column; the long columns (hubs: 10^4 .. 10^6 entries) are handed to k_hybrid_long
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_hybrid_cols(const uint32_t *__restrict__ col, const uint32_t *__restrict__ val, const uint32_t *__restrict__ deg,
+                                                     const unsigned int *__restrict__ n_dev, uint32_t cap, uint32_t big, const uint32_t *__restrict__ JA, const uint32_t *__restrict__ IA,
+                                                     const uint32_t *__restrict__ A, uint32_t *__restrict__ y, uint32_t *__restrict__ long_list, unsigned int *__restrict__ long_n) {
+    constexpr uint32_t LPC = 8, GPB = 256 / LPC;
+    const uint32_t n = min(*n_dev, cap), sub = threadIdx.x & (LPC - 1);
+    for (uint32_t gi = blockIdx.x * GPB + threadIdx.x / LPC; gi < n; gi += gridDim.x * GPB) {
+        const uint32_t d = deg[gi];
+        if (d > big) { if (sub == 0) long_list[atomicAdd(long_n, 1u)] = gi; continue; }
+        const uint32_t e0 = JA[col[gi]], m0 = val[gi];
+        for (uint32_t k = sub; k < d; k += LPC) {
+            const uint32_t r = IA[e0 + k];
+            const uint32_t m = WEIGHTED ? m0 + A[e0 + k] : m0;
+            if (m < y[r]) atomicMin(&y[r], m);
+        }
+    }
+}
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_hybrid_long(const uint32_t *__restrict__ long_list, const unsigned int *__restrict__ long_n, const uint32_t *__restrict__ col,
+                                                     const uint32_t *__restrict__ val, const uint32_t *__restrict__ deg, const uint32_t *__restrict__ JA,
+                                                     const uint32_t *__restrict__ IA, const uint32_t *__restrict__ A, uint32_t *__restrict__ y) {
+    // a long column is cut into pieces of 4096 entries, a workgroup per piece (blockIdx.y = the piece's position among gridDim.y)
+    const uint32_t n = *long_n;
+    for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {
+        const uint32_t gi = long_list[li], d = deg[gi], e0 = JA[col[gi]], m0 = val[gi];
+        for (uint32_t k = blockIdx.y * 256 + threadIdx.x; k < d; k += gridDim.y * 256) {
+            const uint32_t r = IA[e0 + k];
+            const uint32_t m = WEIGHTED ? m0 + A[e0 + k] : m0;
+            if (m < y[r]) atomicMin(&y[r], m);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ phase 1
 // T  = type of y and of the LDS accumulators (double or uint32_t)
 // TV = type of the value stream VAL and of the LDS message window: T, or float for the
@@ -642,7 +761,8 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
-                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end) {
+                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end,
+                                                           const uint8_t *__restrict__ win_mode) {
     static_assert(W + 1 == WS, "dense and sparse chunks share one LDS window");
     __shared__ TV xwin[WS];
     // the outputs of a wave's 256-entry group, dense, before they leave in coalesced stores: four predicated dword stores per lane
@@ -661,6 +781,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // ONE launch for both kinds of chunks (dense ones first, largest first; the light sparse ones fill the tail): two launches
     // cost a drain of the 64-KiB workgroups in between
     const bool sparse = col0 >= dense_end;
+    if constexpr (IS_MIN) {
+        // hybrid pass (pb_run): a window whose few active columns went to the column-driven SpMSpV -- or that has none -- is left out
+        // here without even staging it; its value-stream slots keep older messages of the same program (y is a running min)
+        if (win_mode) {
+            const uint32_t q = sparse ? dense_end / W + (col0 - dense_end) / WS : col0 / W;
+            if (win_mode[q] != 0) { if (threadIdx.x == 0 && chunk_active) chunk_active[c] = 0u; return; }
+        }
+    }
     const uint32_t wlim = sparse ? WS : W;
     const uint32_t wn = (ncols - col0 < wlim) ? ncols - col0 : wlim;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
@@ -926,6 +1054,18 @@ struct gt_pb {
     // still run (gt_program_phase2_part, dist.hip). work[work_part[k] .. work_part[k+1]) (largest first inside a part),
     // split_bins[split_part[k] .. split_part[k+1]).
     std::vector<uint32_t> work_part, split_part;
+    // per window of x: stored entries (both row classes), for the activity statistics / the hybrid pass of the min programs
+    uint32_t *win_entries = nullptr; uint32_t nwin = 0; uint32_t ndw_ = 0, dense_end_ = 0;
+    uint32_t *xdeg = nullptr;          // [x_len] entries of the column in slot sl (0 for an unused slot)
+    unsigned long long *win_act = nullptr;   // [nwin] scratch: entries of the ACTIVE columns of every window
+    // HYBRID pass of the min programs (pb_run): windows whose active columns hold at most 1/32 of their entries are left out of
+    // the streaming pass; those columns' entries go through a column-driven SpMSpV (atomicMin on y) instead
+    uint8_t *win_mode = nullptr;             // [nwin] 0 = stream, 1 = its active columns go to the SpMSpV, 2 = no active column
+    uint32_t *hy_col = nullptr, *hy_val = nullptr, *hy_deg = nullptr, *hy_long = nullptr;   // [hy_cap] the columns of the mode-1 windows; indices of the long ones
+    uint32_t hy_cap = 0;
+    uint32_t *hy_cand = nullptr; uint32_t hy_ncand = 0;   // the candidate windows (at least nnz / 256 entries each)
+    unsigned int *hy_cnt = nullptr;          // [2] columns listed, long columns among them
+    unsigned long long *hy_stat = nullptr;   // [4] running totals: hybrid passes, entries left to the SpMSpV, entries left out of the stream, windows left out
     uint32_t rows_single = 0;           // rows of those bins
     const void *val_owner = nullptr;   // program (and its initialize epoch) whose messages VAL currently holds
     uint64_t val_epoch = 0;
@@ -935,7 +1075,8 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single, pb->split_bins};
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single, pb->split_bins,
+                    pb->win_entries, pb->xdeg, pb->win_act, pb->win_mode, pb->hy_col, pb->hy_val, pb->hy_deg, pb->hy_long, pb->hy_cnt, pb->hy_stat, pb->hy_cand};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : pb->pt_ev) (void)hipEventDestroy(e);
     delete pb;
@@ -1401,9 +1542,43 @@ int gt_pb_build(gt_graph *g) {
         PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
         PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
     }
+    {   // window statistics for the min programs' hybrid pass (cheap: a few MB)
+        pb->nwin = geom.nwin; pb->ndw_ = geom.ndw; pb->dense_end_ = geom.dense_end;
+        PB_MALLOC(pb->win_entries, (uint64_t)geom.nwin * 4); PB_MALLOC(pb->win_act, (uint64_t)geom.nwin * 8); PB_MALLOC(pb->xdeg, (uint64_t)std::max(g->x_len, 1u) * 4);
+        k_win_total<<<grid_for(geom.nwin), TPB, 0, s>>>(wcount.as<uint32_t>(), geom.nwin, geom.ncls, pb->win_entries);
+        k_slot_degrees<<<grid_for(g->x_len), TPB, 0, s>>>(g->JA, g->xcol, g->x_len, pb->xdeg);
+    }
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
     g->pb = pb;
+    return GT_OK;
+}
+
+// GRAPHTAP_WINDOW_ACTIVITY=1 (diagnostic; a host round trip per call): for the message vector a streaming pass of a min program
+// is about to read, how the stored entries divide over windows by the fraction of them that belongs to ACTIVE columns. Printed to
+// stderr; what a per-window choice between the streaming pass and the column-driven SpMSpV would have to work with.
+int gt_pb_window_activity_report(const gt_graph *g, const void *x, hipStream_t s, uint32_t iteration) {
+    gt_pb *pb = g->pb;
+    if (!pb || !pb->win_entries || pb->nnz == 0) return GT_OK;
+    WinGeom geom{}; geom.ndw = pb->ndw_; geom.dense_end = pb->dense_end_; geom.nwin = pb->nwin; geom.x_len = g->x_len; geom.ncls = 1; geom.nvwin = pb->nwin;
+    GT_HIP(hipMemsetAsync(pb->win_act, 0, (uint64_t)pb->nwin * 8, s));
+    k_window_activity<<<grid_for(g->x_len), 256, 0, s>>>((const uint32_t *)x, pb->xdeg, g->x_len, geom, pb->win_act);
+    std::vector<unsigned long long> act(pb->nwin); std::vector<uint32_t> tot(pb->nwin);
+    GT_HIP(hipMemcpyAsync(act.data(), pb->win_act, (uint64_t)pb->nwin * 8, hipMemcpyDeviceToHost, s));
+    GT_HIP(hipMemcpyAsync(tot.data(), pb->win_entries, (uint64_t)pb->nwin * 4, hipMemcpyDeviceToHost, s));
+    GT_HIP(hipStreamSynchronize(s));
+    const double cut[] = {0.0, 1.0 / 64, 1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0 / 2, 1.01};
+    unsigned long long te[8] = {0}, ta[8] = {0}, nw[8] = {0}, all_e = 0, all_a = 0;
+    for (uint32_t q = 0; q < pb->nwin; q++) {
+        if (!tot[q]) continue;
+        const double f = (double)act[q] / tot[q];
+        int b = 0;
+        if (act[q]) { b = 1; while (b < 7 && f > cut[b]) b++; }
+        te[b] += tot[q]; ta[b] += act[q]; nw[b]++; all_e += tot[q]; all_a += act[q];
+    }
+    fprintf(stderr, "[activity] iteration %u: %llu of %llu entries belong to active columns (%.1f %%); windows by active fraction:\n", iteration, all_a, all_e, 100.0 * all_a / std::max(all_e, 1ull));
+    const char *names[] = {"none active", "<= 1/64", "<= 1/32", "<= 1/16", "<= 1/8", "<= 1/4", "<= 1/2", "> 1/2"};
+    for (int b = 0; b < 8; b++) if (nw[b]) fprintf(stderr, "[activity]   %-12s %6llu windows, %12llu entries (%5.1f %% of all), %12llu of them active\n", names[b], nw[b], te[b], 100.0 * te[b] / std::max(all_e, 1ull), ta[b]);
     return GT_OK;
 }
 
@@ -1426,13 +1601,40 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         while (pb->pt_ev.size() < pb->pt_used + 3) { hipEvent_t e; GT_HIP(hipEventCreate(&e)); pb->pt_ev.push_back(e); }
         GT_HIP(hipEventRecord(pb->pt_ev[pb->pt_used], s));
     }
+    const uint8_t *win_mode = nullptr;
+    if constexpr (IS_MIN) {
+        // HYBRID pass: in the middle iterations of SSSP / CC the frontier is millions of columns, yet whole hub windows hold only a
+        // few active ones (R-MAT-26, SSSP iteration 4: 19 windows with 37 % + 19 % of all entries have none / at most 1/64 of them
+        // in active columns; profiles/r04/window_activity_sssp_cc.txt). One pass over x counts the entries of the active columns
+        // per window; the windows at or below 1/32 (bounded to nnz/64 entries in all) hand those columns to a column-driven SpMSpV
+        // (atomicMin on y) and their chunks leave the streaming pass. No host round trip: every count stays on the device.
+        // BUILT, MEASURED, OFF BY DEFAULT (GRAPHTAP_HYBRID=1 switches it on; profiles/r04/ab_hybrid_pass.txt, two rounds on one box): the
+        // pass leaves out what the table promised -- R-MAT-26 SSSP: 406 M of the 4.2 G entries its four streaming passes touch, 1.06 M
+        // entries through the column kernels -- and buys 1 %: SSSP R-MAT-26 10.02 -> 9.92 / 9.59 -> 9.47 ms, CC stand-in 6.06 -> 5.89 /
+        // 6.16 -> 6.14, CC R-MAT-26 7.67 -> 7.50 / 7.54 -> 7.82, SSSP R-MAT-24 2.82 -> 2.92 (its four extra enqueues per pass cost more
+        // than the 47 % of iteration 4 it skips). The hub windows it removes are the CHEAP part of a min pass (12 entries per
+        // value-stream slot: little store traffic), and phase 2 still streams every slot of a bin that any chunk fed.
+        const bool hybrid_on = getenv("GRAPHTAP_HYBRID") && atoi(getenv("GRAPHTAP_HYBRID")) != 0;   // (read per call: the tests run both ways in one process)
+        if (hybrid_on && filter && pb->win_mode && pb->hy_ncand && g->info.x_slices == 1 && !gt_has_exchange(g) &&
+            phases == (GT_PB_PREPARE | GT_PB_PHASE1 | GT_PB_PHASE2)) {
+            WinGeom geom{}; geom.ndw = pb->ndw_; geom.dense_end = pb->dense_end_; geom.nwin = pb->nwin; geom.x_len = g->x_len; geom.ncls = 1; geom.nvwin = pb->nwin;
+            const char *ef = getenv("GRAPHTAP_HYBRID_F");   // (tests: 1 = every candidate window with an active column goes through the column-driven kernels)
+            const unsigned long long F = ef ? std::max(1, atoi(ef)) : 32;
+            GT_HIP(hipMemsetAsync(pb->hy_cnt, 0, 2 * sizeof(unsigned int), s));
+            k_hybrid_windows<<<pb->hy_ncand, 1024, 0, s>>>(pb->hy_cand, (const uint32_t *)x, g->xcol, pb->xdeg, g->x_len, geom, pb->win_entries, F, pb->win_mode, pb->hy_cnt,
+                                                            pb->hy_cap, pb->hy_col, pb->hy_val, pb->hy_deg, pb->hy_stat);
+            k_hybrid_cols<WEIGHTED><<<std::min<uint32_t>(2048u, std::max<uint32_t>(pb->hy_cap / 32, 1u)), 256, 0, s>>>(pb->hy_col, pb->hy_val, pb->hy_deg, pb->hy_cnt, pb->hy_cap, 1024u, g->JA, g->IA, g->A, (uint32_t *)y, pb->hy_long, pb->hy_cnt + 1);
+            k_hybrid_long<WEIGHTED><<<dim3(64, 32), 256, 0, s>>>(pb->hy_long, pb->hy_cnt + 1, pb->hy_col, pb->hy_val, pb->hy_deg, g->JA, g->IA, g->A, (uint32_t *)y);
+            win_mode = pb->win_mode;
+        }
+    }
     if (phases & GT_PB_PHASE1) {
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
         auto scatter = [&](uint32_t c0, uint32_t c1) {
             if (c1 > c0)
                 k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
                     pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W);
+                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W, win_mode);
         };
         // one launch: [regular rows: dense, sparse][source rows: dense, sparse]; computation filtering (TCSC_CF) leaves the
         // source rows' chunks out of every iteration but the last
@@ -1507,6 +1709,17 @@ uint32_t gt_pb_val_allocs(const gt_graph *g) { return g->pb ? g->pb->val_allocs 
 
 const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
 const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n) { *n = g->pb ? g->pb->nsplit : 0; return g->pb ? g->pb->split_bins : nullptr; }
+// running totals of the hybrid passes of this graph: [0] passes, [1] entries handed to the column-driven kernels, [2] entries of the
+// windows left out of the streaming pass, [3] such windows (diagnostic; tools/bench_apps.py)
+extern "C" int gt_graph_hybrid_stats(const gt_graph *g, uint64_t *out4, int reset) {
+    GT_REQUIRE(g && out4, GT_ERR_INVALID, "null argument");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!g->pb || !g->pb->hy_stat) return GT_OK;
+    GT_HIP(hipDeviceSynchronize());
+    GT_HIP(hipMemcpy(out4, g->pb->hy_stat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) GT_HIP(hipMemset(g->pb->hy_stat, 0, 4 * sizeof(unsigned long long)));
+    return GT_OK;
+}
 uint32_t gt_pb_parts(const gt_graph *g) { return g->pb && !g->pb->work_part.empty() ? (uint32_t)g->pb->work_part.size() - 1 : 1; }
 const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n) {   // the split bins of part k of the phase-2 work list
     *n = 0;
@@ -1523,6 +1736,23 @@ int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hi
     gt_pb *pb = g->pb;
     if (!pb || pb->nnz == 0 || !pb->VAL) return GT_OK;
     if (pb->val_bytes != 4 || pb->val_kind != 3) { pb->val_bytes = 4; pb->val_kind = 3; }
+    if (!pb->win_mode && pb->nwin && !gt_has_exchange(g)) {   // the buffers of the hybrid pass (pb_run): here, not inside the iteration loop
+        // candidates: the windows that hold at least 1/256 of all entries each (GRAPHTAP_HYBRID_MIN_DIV; tests: a huge divisor = every window)
+        const char *ed = getenv("GRAPHTAP_HYBRID_MIN_DIV");
+        const uint64_t div = ed ? (uint64_t)std::max(1ll, atoll(ed)) : 256;
+        std::vector<uint32_t> tot(pb->nwin), cand;
+        GT_HIP(hipMemcpy(tot.data(), pb->win_entries, (uint64_t)pb->nwin * 4, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < pb->nwin; q++) if (tot[q] && (uint64_t)tot[q] * div >= pb->nnz) cand.push_back(q);
+        GT_HIP(hipMalloc((void **)&pb->win_mode, pb->nwin)); GT_HIP(hipMemsetAsync(pb->win_mode, 0, pb->nwin, s));   // everything else streams
+        pb->hy_ncand = (uint32_t)cand.size();
+        if (pb->hy_ncand) {
+            pb->hy_cap = (uint32_t)std::min<uint64_t>((uint64_t)pb->hy_ncand * WS, 1u << 26);   // (a listed column is a slot of a candidate window)
+            GT_HIP(hipMalloc((void **)&pb->hy_cand, (uint64_t)pb->hy_ncand * 4)); GT_HIP(hipMemcpy(pb->hy_cand, cand.data(), (uint64_t)pb->hy_ncand * 4, hipMemcpyHostToDevice));
+            GT_HIP(hipMalloc((void **)&pb->hy_cnt, 2 * sizeof(unsigned int)));
+            GT_HIP(hipMalloc((void **)&pb->hy_stat, 4 * sizeof(unsigned long long))); GT_HIP(hipMemsetAsync(pb->hy_stat, 0, 4 * sizeof(unsigned long long), s));
+            for (uint32_t **q : {&pb->hy_col, &pb->hy_val, &pb->hy_deg, &pb->hy_long}) GT_HIP(hipMalloc((void **)q, (uint64_t)pb->hy_cap * 4));
+        }
+    }
     k_fill_t<uint32_t><<<grid_for(pb->nout), TPB, 0, s>>>((uint32_t *)pb->VAL, pb->nout, GT_INF);
     GT_HIP(hipGetLastError());
     pb->val_min = 1; pb->val_owner = owner; pb->val_epoch = epoch;

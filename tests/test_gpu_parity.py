@@ -440,6 +440,46 @@ def test_frontier_lists_are_bit_exact(gt, O, lists, spmspv, known_answers, monke
     if lists == "1": assert got["stats"].list_iterations > 0   # the tail iterations of CC
 
 
+@pytest.mark.parametrize("mode", ["all", "f2", "default", "off"])
+def test_hybrid_streaming_pass_is_bit_exact(gt, O, mode, known_answers, monkeypatch):
+    """The hybrid pass of the min programs (pb.hip, pb_run; round 4): the heavy windows of x (candidates: at least 1/256 of all
+    entries each) whose active columns hold a small fraction of their entries leave the streaming pass -- those columns' entries go
+    through column-driven kernels (atomicMin on y), the short columns eight lanes each, the long ones a workgroup per 8 192 entries
+    -- decided per window on the device, no host round trip. Labels, distances, parents AND iteration counts must be the
+    reference's / the oracle's with EVERY window with an active column sent that way ("all": every window a candidate, threshold
+    1), with a low threshold ("f2": a mix of streamed and column-driven windows), by default and with the pass switched off; the sparse paths that would otherwise take the small frontiers are forbidden so that every iteration is a
+    (hybrid) streaming pass, bottom-up BFS steps and CC's first-entry shortcut included in the forbidden ones."""
+    from graphtap_amd.rmat import rmat_edges
+    L = gt._lib.lib()
+    if mode == "all": monkeypatch.setenv("GRAPHTAP_HYBRID_F", "1"); monkeypatch.setenv("GRAPHTAP_HYBRID_MIN_DIV", "4000000000")   # every window is a candidate
+    if mode == "f2": monkeypatch.setenv("GRAPHTAP_HYBRID_F", "2"); monkeypatch.setenv("GRAPHTAP_HYBRID_MIN_DIV", "4000000000")
+    monkeypatch.setenv("GRAPHTAP_HYBRID", "0" if mode == "off" else "1")   # (off by default: measured, +-1 %)
+    for k in ("GRAPHTAP_SPMSPV", "GRAPHTAP_BFS_BOTTOM_UP", "GRAPHTAP_CC_FIRST", "GRAPHTAP_TAIL_KERNEL"): monkeypatch.setenv(k, "0")
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
+        r = run_min(gt, "bfs", c["edges"], nv, c["root"])
+        assert (r["parent"][:n] == c["np1_bfs_a"]).all() and (r["hops"][:n] == c["np1_bfs_b"]).all() and r["iterations"] == k["np1_bfs"]["iterations"]
+        r = run_min(gt, "sssp", c["wedges"], nv, c["root"])
+        assert (r["distance"][:n] == c["np1_sssp_a"]).all() and r["iterations"] == k["np1_sssp"]["iterations"]
+        r = run_min(gt, "cc", c["edges"], nv)
+        assert (r["label"][:n] == c["np1_cc_a"]).all() and r["iterations"] == k["np1_cc"]["iterations"]
+    raw = C.CDLL(gt._lib.LIB_PATH); raw.gt_graph_hybrid_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    w = rmat_edges(18, 16, 9, weighted=True); e = np.ascontiguousarray(w[:, :2]); nv = 1 << 18
+    seen = {}
+    for app, edges, flags, root in (("sssp", w, (True, True, False, False, False), 0), ("cc", e, (False, False, True, False, False), 0), ("bfs", e, (False, False, False, False, False), 5)):
+        want = O.run_app(app, edges, nv, root=root) if app != "cc" else O.run_app(app, edges, nv)
+        G = gt.Graph(weighted=(app == "sssp")); G.load_edges(edges, nv, nv, *flags, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+        P = {"bfs": gt.BFS_Program, "cc": gt.CC_Program, "sssp": gt.SSSP_Program}[app](G, False, app != "bfs", app == "bfs", gt._ROW_)
+        P.root = root; P.execute()
+        key = {"bfs": "parent", "cc": "label", "sssp": "distance"}[app]
+        assert (P.V[key] == want[key]).all() and P.iteration == want["iterations"], app
+        st = (C.c_uint64 * 4)(); gt._lib.check(raw.gt_graph_hybrid_stats(G._h, st, 0)); seen[app] = tuple(int(v) for v in st)
+        P.free(); G.free(); want["graph"].close()
+    print("hybrid mode %s: (passes, entries to the column kernels, entries left out of the stream, windows left out) per app: %s" % (mode, seen))
+    if mode == "off": assert all(v[0] == 0 for v in seen.values())
+    if mode == "all": assert all(v[0] > 0 and v[1] > 0 and v[2] > 0 for v in seen.values()), seen
+
+
 @pytest.mark.parametrize("early", [None, "0", "collect"])
 @pytest.mark.parametrize("mode", ["1", "0", None])
 def test_bfs_bottom_up_steps_are_bit_exact(gt, O, mode, early, known_answers, monkeypatch):

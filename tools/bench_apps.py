@@ -83,10 +83,17 @@ for app in args.apps.split(","):
     warm = P.stats.seconds
     assert P.checksum(out=None) == cs and P.stats.iterations == st.iterations
     extra = {}
+    try:   # the hybrid passes of the two timed runs (engine-internal diagnostic, csrc/pb.hip)
+        raw = C.CDLL(_lib.LIB_PATH); raw.gt_graph_hybrid_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        hs = (C.c_uint64 * 4)(); _lib.check(raw.gt_graph_hybrid_stats(G._h, hs, 1))
+        extra_h = {"hybrid": {"passes": int(hs[0]) // 2, "entries_to_column_kernels": int(hs[1]) // 2, "entries_left_out_of_the_stream": int(hs[2]) // 2, "windows_left_out": int(hs[3]) // 2}}
+    except Exception:
+        extra_h = {}
     if app != "deg":
         req, per_it = required_bytes(L, G, P, app)
         assert len(per_it) == st.iterations, (len(per_it), st.iterations)
         extra = {"required_bytes": req, "required_GBps": req / st.seconds / 1e9, "required_frac": req / st.seconds / 8e12, "required_frac_warm": req / warm / 8e12, "per_iteration": per_it}
+    extra.update(extra_h)
     print(json.dumps({"app": app, "scale": scale, "edge_factor": args.edge_factor, "root": int(P.root), "spmv": os.environ.get("GRAPHTAP_SPMV", "pb"), "stored_entries": int(G.info.nnz_local),
                       "iterations": st.iterations, "sparse_iterations": int(st.spmspv_iterations), "execute_s": st.seconds, "GTEPS": G.info.nnz_local * st.iterations / st.seconds / 1e9,
                       "execute_warm_s": warm, "GTEPS_warm": G.info.nnz_local * st.iterations / warm / 1e9, "list_iterations": int(st.list_iterations),
