@@ -62,6 +62,37 @@ class ExecStats(C.Structure):
                 ("allocs_in_execute", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
+class GraphOptions(C.Structure):
+    """gt_graph_options: per-handle configuration of a graph build (unset fields fall back to the environment)."""
+    _fields_ = [("size", C.c_uint32), ("spmv_variant", C.c_int32), ("force_exchange", C.c_int32), ("x_slices", C.c_uint32),
+                ("hubs_first", C.c_int32), ("hub_min_degree", C.c_uint32), ("exchange_hub_min", C.c_uint32), ("chunk_log2", C.c_uint32),
+                ("reserved", C.c_uint32 * 8)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().gt_graph_options_init(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("gt_graph_options has no field " + k)
+            setattr(self, k, v)
+
+
+class ProgramOptions(C.Structure):
+    """gt_program_options: per-handle configuration of a program (unset fields fall back to the graph's, then the environment)."""
+    _fields_ = [("size", C.c_uint32), ("frontier_lists", C.c_int32), ("spmspv", C.c_int32), ("tail_kernel", C.c_int32),
+                ("bfs_bottom_up", C.c_int32), ("cc_first", C.c_int32), ("fuse_apply", C.c_int32), ("lean_state", C.c_int32), ("hybrid", C.c_int32),
+                ("spmspv_fraction", C.c_uint32), ("tail_list_max", C.c_uint32), ("tail_entries_max", C.c_uint32), ("reserved0", C.c_uint32),
+                ("timeout_s", C.c_double), ("reserved", C.c_uint32 * 8)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().gt_program_options_init(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("gt_program_options has no field " + k)
+            setattr(self, k, v)
+
+
 # every symbol include/graphtap_amd.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SIGNATURES = {
@@ -71,6 +102,10 @@ SIGNATURES = {
     "gt_set_device": (C.c_int, [C.c_int]),
     "gt_graph_build": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int]),
     "gt_graph_build_distributed": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags)]),
+    "gt_graph_options_init": (None, [C.POINTER(GraphOptions)]),
+    "gt_program_options_init": (None, [C.POINTER(ProgramOptions)]),
+    "gt_graph_build_opt": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int, C.POINTER(GraphOptions)]),
+    "gt_program_set_options": (C.c_int, [_vp, C.POINTER(ProgramOptions)]),
     "gt_graph_info_get": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
     "gt_graph_select_spmv": (C.c_int, [_vp, C.c_int]),
     "gt_graph_vertex_ids": (C.c_int, [_vp, _vp, C.c_uint64]),

@@ -398,10 +398,10 @@ int gt_graph_free(gt_graph *g) {
 }
 
 static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
-                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist);
+                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist, const gt_graph_options *opt);
 int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
                    uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks) {
-    return graph_build_impl(out, edges, m, edges_on_device, weighted, num_vertices, flags, rank, nranks, nullptr);
+    return graph_build_impl(out, edges, m, edges_on_device, weighted, num_vertices, flags, rank, nranks, nullptr, nullptr);
 }
 // Matrix::distribute (mat/matrix.hpp:693-810): every rank brings a SHARE of the records (any split of the list); the build moves
 // each record to the owner of its row(s) and gets the global pieces from collectives over `dist`. Collective: every rank of the
@@ -409,10 +409,29 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
 int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_share, uint64_t m_share, int edges_on_device, int weighted,
                                uint32_t num_vertices, const gt_graph_flags *flags) {
     GT_REQUIRE(dist, GT_ERR_INVALID, "gt_graph_build_distributed: null communicator");
-    return graph_build_impl(out, edges_share, m_share, edges_on_device, weighted, num_vertices, flags, gt_dist_rank(dist), gt_dist_nranks(dist), dist);
+    return graph_build_impl(out, edges_share, m_share, edges_on_device, weighted, num_vertices, flags, gt_dist_rank(dist), gt_dist_nranks(dist), dist, nullptr);
+}
+// ---- handle-level configuration (include/graphtap_amd.h): a field that is set becomes an override of the environment variable it
+// names, stored in the handle (gt_overrides); every site that reads such a knob asks gt_cfg(handle, name)
+void gt_graph_options_init(gt_graph_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->size = (uint32_t)sizeof(*o); o->spmv_variant = -1; o->force_exchange = -1; o->hubs_first = -1;
+}
+void gt_program_options_init(gt_program_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->size = (uint32_t)sizeof(*o);
+    o->frontier_lists = o->spmspv = o->tail_kernel = o->bfs_bottom_up = o->cc_first = o->fuse_apply = o->lean_state = o->hybrid = -1;
+}
+int gt_graph_build_opt(gt_graph **out, gt_dist *dist, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                       uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, const gt_graph_options *opt) {
+    GT_REQUIRE(!opt || opt->size >= 8, GT_ERR_INVALID, "gt_graph_options: size is not set (gt_graph_options_init)");
+    if (dist) { rank = gt_dist_rank(dist); nranks = gt_dist_nranks(dist); }
+    return graph_build_impl(out, edges, m, edges_on_device, weighted, num_vertices, flags, rank, nranks, dist, opt);
 }
 static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int edges_on_device, int weighted,
-                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist) {
+                            uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, gt_dist *dist, const gt_graph_options *opt_in) {
     GT_REQUIRE(out && flags && (edges || m == 0), GT_ERR_INVALID, "gt_graph_build: null argument");
     GT_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, GT_ERR_INVALID, "gt_graph_build: rank %d of %d", rank, nranks);
     GT_REQUIRE(num_vertices < 0xFFFFFFF0u - (uint32_t)nranks, GT_ERR_INVALID, "num_vertices too large for 32-bit vertex ids");
@@ -420,6 +439,20 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
     *out = nullptr;
     gt_graph *g = new gt_graph();
     { static std::atomic<uint64_t> serials{0}; g->serial = ++serials; }
+    if (opt_in) {   // only the fields the caller's struct has (its `size`), only the ones that are set
+        gt_graph_options o; gt_graph_options_init(&o);
+        memcpy(&o, opt_in, std::min<size_t>(opt_in->size, sizeof(o)));
+        if (o.spmv_variant >= 0) {
+            if (o.spmv_variant > GT_SPMV_PB_F32MSG) { delete g; gt_set_error("gt_graph_options: unknown SpMV variant %d", o.spmv_variant); return GT_ERR_INVALID; }
+            g->cfg.set("GRAPHTAP_SPMV", o.spmv_variant == GT_SPMV_EDGE ? "edge" : o.spmv_variant == GT_SPMV_PB_F32MSG ? "pb_f32msg" : "pb");
+        }
+        if (o.force_exchange >= 0) g->cfg.set("GRAPHTAP_FORCE_EXCHANGE", o.force_exchange ? "1" : "0");
+        if (o.x_slices) g->cfg.set("GRAPHTAP_X_SLICES", std::to_string(o.x_slices));
+        if (o.hubs_first >= 0) g->cfg.set("GRAPHTAP_PB_HUBS", o.hubs_first ? "1" : "0");
+        if (o.hub_min_degree) g->cfg.set("GRAPHTAP_PB_HUB_DEG", std::to_string(o.hub_min_degree));
+        if (o.exchange_hub_min) g->cfg.set("GRAPHTAP_EXCHANGE_HUB_MIN", std::to_string(o.exchange_hub_min));
+        if (o.chunk_log2) g->cfg.set("GRAPHTAP_PB_CH", std::to_string(o.chunk_log2));
+    }
     g->flags = *flags;
     g->info.num_vertices = num_vertices;
     g->info.nrows = num_vertices + 1;                          // mat/graph.hpp:89-90
@@ -429,7 +462,7 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
     // contiguous ranges of a multiplicatively hashed INTERNAL id space (a bijection on the next power of
     // two; results are reported in original ids, see gt_graph_vertex_ids).
     g->nint = g->info.nrows;
-    { const char *fe = getenv("GRAPHTAP_FORCE_EXCHANGE"); g->force_exchange = fe != nullptr && atoi(fe) != 0; }
+    { const char *fe = gt_cfg(g, "GRAPHTAP_FORCE_EXCHANGE"); g->force_exchange = fe != nullptr && atoi(fe) != 0; }
     if (nranks > 1) {
         uint32_t M = 1; while (M < g->info.nrows && M < 0x80000000u) M <<= 1;
         GT_REQUIRE(M >= g->info.nrows, GT_ERR_UNSUPPORTED, "more than 2^31 vertices on several ranks");
@@ -466,7 +499,7 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
     tick("ingest (TCSC tile-row)", tb);
     if (staged) (void)hipFree(staged);
     if (st != GT_OK) { gt_scratch_release(); gt_graph_free(g); return st; }
-    const char *env = getenv("GRAPHTAP_SPMV");
+    const char *env = gt_cfg(g, "GRAPHTAP_SPMV");
     // default: propagation blocking with f64 messages. pb_f32msg (PageRank's messages rounded to f32 in fixed-count runs: 5e-8 of
     // relative rank error, tolerance 1e-6) stays opt-in: made the default in round 3 it flipped the sixth decimal of one printed
     // rank between two layouts (1.425146 / 1.425145) -- the mains must print the reference's lines digit for digit
@@ -575,6 +608,22 @@ int gt_program_free(gt_program *p) {
     return GT_OK;
 }
 
+int gt_program_set_options(gt_program *p, const gt_program_options *opt) {
+    GT_REQUIRE(p && opt && opt->size >= 8, GT_ERR_INVALID, "gt_program_set_options: null argument, or size is not set (gt_program_options_init)");
+    gt_program_options o; gt_program_options_init(&o);
+    memcpy(&o, opt, std::min<size_t>(opt->size, sizeof(o)));
+    auto flag = [&](int32_t v, const char *name) { if (v >= 0) p->cfg.set(name, v ? "1" : "0"); };
+    flag(o.frontier_lists, "GRAPHTAP_FRONTIER_LISTS"); flag(o.spmspv, "GRAPHTAP_SPMSPV"); flag(o.tail_kernel, "GRAPHTAP_TAIL_KERNEL");
+    flag(o.bfs_bottom_up, "GRAPHTAP_BFS_BOTTOM_UP"); flag(o.cc_first, "GRAPHTAP_CC_FIRST"); flag(o.fuse_apply, "GRAPHTAP_FUSE_APPLY");
+    flag(o.lean_state, "GRAPHTAP_PR_LEAN_STATE"); flag(o.hybrid, "GRAPHTAP_HYBRID");
+    if (o.spmspv_fraction) p->cfg.set("GRAPHTAP_SPMSPV_FRACTION", std::to_string(o.spmspv_fraction));
+    if (o.tail_list_max) p->cfg.set("GRAPHTAP_TAIL_LIST", std::to_string(o.tail_list_max));
+    if (o.tail_entries_max) p->cfg.set("GRAPHTAP_TAIL_ENTRIES", std::to_string(o.tail_entries_max));
+    if (o.timeout_s > 0) p->timeout_s = o.timeout_s;
+    // (the frontier lists are sized by initialize(): a program that switches them on afterwards gets them at its next initialize())
+    return GT_OK;
+}
+
 int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *prm) {
     GT_REQUIRE(out && g && prm, GT_ERR_INVALID, "null argument");
     GT_REQUIRE(prm->kind >= GT_DEG && prm->kind <= GT_CC, GT_ERR_INVALID, "unknown program kind %d", prm->kind);
@@ -609,7 +658,7 @@ int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *pr
     if (ok && prm->kind == GT_BFS) ok = hipMalloc((void **)&p->s1, (uint64_t)H * 4) == hipSuccess;
     {   // frontier lists of the min programs: the vertices the last apply changed (on several ranks: the rank's own, local ids;
         // the C++ driver turns them into (index, value) pairs for the peers and runs the SpMSpV from the pairs it receives, dist.hip)
-        const char *fe = getenv("GRAPHTAP_FRONTIER_LISTS");
+        const char *fe = gt_cfg(p, "GRAPHTAP_FRONTIER_LISTS");
         p->fl_enabled = !p->stationary && prm->order == GT_ROW && !(fe && atoi(fe) == 0);
         if (ok && p->fl_enabled) {
             p->fl_rows_cap = std::max<uint32_t>(g->info.nnzrows, 1);
@@ -908,7 +957,7 @@ static int gt_timing_event(gt_program *p, hipStream_t s, hipEvent_t *out) {
         // the pairs recorded so far are folded into a running sum and their events used again (a drain of the stream every
         // 32 SpMVs; no event is created inside the iteration loop). Only at a pair boundary: a sliced SpMV holds one open.
         if ((p->ev_used & 1) == 0) {
-            { int st = gt_stream_wait_deadline(s, "the iteration loop (timing events)"); if (st != GT_OK) return st; }
+            { int st = gt_stream_wait_deadline(s, "the iteration loop (timing events)", p->timeout_s); if (st != GT_OK) return st; }
             for (size_t i = 0; i + 1 < p->ev_used; i += 2) { float ms = 0; GT_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1])); p->ev_acc_ms += ms; p->ev_acc_pairs++; }
             p->ev_used = 0;
         } else { hipEvent_t a; GT_HIP(hipEventCreate(&a)); p->ev.push_back(a); }
@@ -1106,13 +1155,13 @@ int gt_program_phase2_part(gt_program *p, uint32_t k, uint32_t num_iterations, i
     return GT_OK;
 }
 
-static bool fuse_enabled() {
-    const char *e = getenv("GRAPHTAP_FUSE_APPLY");
+static bool fuse_enabled(const gt_program *p) {
+    const char *e = gt_cfg(p, "GRAPHTAP_FUSE_APPLY");
     return !(e != nullptr && atoi(e) == 0);   // on by default
 }
 int gt_program_fuse_apply(gt_program *p, uint32_t num_iterations, int want_active) {
     GT_REQUIRE(p && p->initialized, GT_ERR_STATE, "fuse_apply before initialize");
-    p->fuse_armed = fuse_enabled() && p->prm.kind == GT_PR && !p->converged;
+    p->fuse_armed = fuse_enabled(p) && p->prm.kind == GT_PR && !p->converged;
     p->fuse_iters = num_iterations; p->fuse_count = want_active != 0; p->cf_hint = true;
     return GT_OK;
 }
@@ -1259,10 +1308,10 @@ int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hi
     static const bool plain = getenv("GRAPHTAP_PLAIN_READBACK") != nullptr;   // A/B: pageable copy + hipStreamSynchronize
     if (plain || !p->h_pinned || bytes > 256) {
         GT_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
-        return gt_stream_wait_deadline(s, "the per-iteration read-back");
+        return gt_stream_wait_deadline(s, "the per-iteration read-back", p->timeout_s);
     }
     GT_HIP(hipMemcpyAsync(p->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s));
-    { int st = gt_stream_wait_deadline(s, "the per-iteration read-back"); if (st != GT_OK) return st; }
+    { int st = gt_stream_wait_deadline(s, "the per-iteration read-back", p->timeout_s); if (st != GT_OK) return st; }
     memcpy(dst, p->h_pinned, bytes);
     return GT_OK;
 }
@@ -1277,15 +1326,15 @@ double gt_wait_limit_s(void) {
     const double v = e ? atof(e) : 300.0;
     return v > 0 ? v : 300.0;
 }
-int gt_stream_wait_deadline(hipStream_t s, const char *what) {
-    const double limit = gt_wait_limit_s();
+int gt_stream_wait_deadline(hipStream_t s, const char *what, double limit_s) {
+    const double limit = limit_s > 0 ? limit_s : gt_wait_limit_s();
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return GT_OK;
         if (e != hipErrorNotReady) { gt_set_error("stream failed during %s: %s", what, hipGetErrorString(e)); return GT_ERR_HIP; }
         if ((spins & 255u) == 255u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
-            gt_set_error("%s did not complete within %g s (GRAPHTAP_TIMEOUT_S): a kernel that does not finish, or a device that is gone", what, limit);
+            gt_set_error("%s did not complete within %g s (GRAPHTAP_TIMEOUT_S / gt_program_options.timeout_s): a kernel that does not finish, or a device that is gone", what, limit);
             return GT_ERR_TIMEOUT;
         }
     }
@@ -1333,19 +1382,19 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
     const bool check = p->check_sticky;
     hipStream_t s = p->stream;
     p->ev_used = 0; p->spmv_done = 0; p->spmspv_iters = 0; p->cf_filtered = 0; p->list_iters = 0; p->tail_iters = 0; p->spmspv_allocs = 0; p->ev_acc_ms = 0; p->ev_acc_pairs = 0;
-    { int st = gt_stream_wait_deadline(s, "the work queued before execute()"); if (st != GT_OK) return st; }
+    { int st = gt_stream_wait_deadline(s, "the work queued before execute()", p->timeout_s); if (st != GT_OK) return st; }
     const uint32_t val_allocs0 = gt_pb_val_allocs(p->g);
     const size_t ev0 = p->ev.size();
     auto t0 = std::chrono::steady_clock::now();
     // GRAPHTAP_TIMING=1: drain the stream after every phase so that the three phase timers are device times
     // (the reference's -DTIMING build, vp:640-684, 1018-1054, 1611-1637); off by default: phases overlap host work.
     const bool phase_timing = stats != nullptr && getenv("GRAPHTAP_TIMING") != nullptr;
-    const bool fuse_apply = fuse_enabled();
+    const bool fuse_apply = fuse_enabled(p);
     double t_sg = 0, t_cb = 0, t_ap = 0, q_sg = 0, q_cb = 0, q_ap = 0;
     uint32_t samples = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto lap = [&](std::chrono::steady_clock::time_point &t, double &acc, double &sq) -> int {
-        if (phase_timing) { int st = gt_stream_wait_deadline(s, "a phase of the iteration loop (GRAPHTAP_TIMING)"); if (st != GT_OK) return st; }
+        if (phase_timing) { int st = gt_stream_wait_deadline(s, "a phase of the iteration loop (GRAPHTAP_TIMING)", p->timeout_s); if (st != GT_OK) return st; }
         auto t2 = now(); const double ms = std::chrono::duration<double, std::milli>(t2 - t).count(); acc += ms; sq += ms * ms; t = t2;
         return GT_OK;
     };
@@ -1372,7 +1421,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
             }
         } else if (p->iteration >= iters) break;
     }
-    { int st = gt_stream_wait_deadline(s, "the iteration loop of execute()"); if (st != GT_OK) return st; }   // every wait of execute() has a deadline
+    { int st = gt_stream_wait_deadline(s, "the iteration loop of execute()", p->timeout_s); if (st != GT_OK) return st; }   // every wait of execute() has a deadline
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <chrono>
+#include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/graphtap_amd.h"
@@ -75,8 +77,17 @@ inline void gt_scratch_release() {
     c.free_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// Handle-level configuration: (environment variable name, value) pairs set through gt_graph_options / gt_program_options; a site
+// that used to call getenv("GRAPHTAP_X") asks the handle first (gt_cfg). Values live as long as the handle.
+struct gt_overrides {
+    std::vector<std::pair<std::string, std::string>> kv;
+    void set(const char *name, const std::string &value) { for (auto &e : kv) if (e.first == name) { e.second = value; return; } kv.emplace_back(name, value); }
+    const char *get(const char *name) const { for (const auto &e : kv) if (e.first == name) return e.second.c_str(); return nullptr; }
+};
+
 // Owned tile-row of the reference's p x p grid, in HBM.
 struct gt_graph {
+    gt_overrides cfg;
     gt_graph_info info{};
     gt_graph_flags flags{};
     // TCSC arrays of the tile-row (ds/compressed_column.hpp:287-296)
@@ -124,6 +135,8 @@ struct gt_graph {
     uint64_t serial = 0;         // unique per built graph (a freed graph's address may come back): what a communicator remembers having checked
 };
 
+// the value of knob `name` for a graph / a program: the handle's own setting, else (programs) its graph's, else the environment
+inline const char *gt_cfg(const gt_graph *g, const char *name) { const char *v = g ? g->cfg.get(name) : nullptr; return v ? v : getenv(name); }
 // true when the message vector lives in the LOCAL column space filled by an exchange (several ranks, or forced)
 inline bool gt_has_exchange(const gt_graph *g) { return g->loc2glob != nullptr; }
 // messengers walk the slots of x: slot -> local vertex (~0u = unused slot), and the row -> slot map of PageRank's applicator
@@ -133,6 +146,8 @@ inline const uint32_t *gt_row_slot(const gt_graph *g) { return g->R2X ? g->R2X :
 
 // Replaces Vertex_Program<> (vp:23-209): state in HBM as struct-of-arrays over the owned segment (engine.hip)
 struct gt_program {
+    gt_overrides cfg;
+    double timeout_s = 0;   // gt_program_options::timeout_s (<= 0: GRAPHTAP_TIMEOUT_S / 300 s)
     gt_graph *g = nullptr;
     gt_program_params prm{};
     bool stationary = true;
@@ -240,6 +255,7 @@ struct gt_program {
     hipEvent_t p2_go = nullptr;                     // ... "phase 1 is complete" (recorded on `stream`)
 };
 
+inline const char *gt_cfg(const gt_program *p, const char *name) { const char *v = p ? p->cfg.get(name) : nullptr; return v ? v : gt_cfg(p ? p->g : nullptr, name); }
 #define GT_FRONTIER_CAP (1u << 24)   // longest frontier kept as a list
 #ifndef GT_PB_ROW_BIN_BITS
 #define GT_PB_ROW_BIN_BITS 14   // log2 rows per phase-2 row bin (pb.hip)
@@ -271,7 +287,7 @@ struct gt_pr_epilogue {
 };
 // which of the three the iteration about to run may use (GRAPHTAP_PR_LEAN_STATE=0: always the full one)
 static inline int gt_pr_state_mode(const gt_program *p, uint32_t iters, bool check) {
-    const char *e = getenv("GRAPHTAP_PR_LEAN_STATE");   // read per call: the tests run both ways in one process
+    const char *e = gt_cfg(p, "GRAPHTAP_PR_LEAN_STATE");   // read per call: the tests run both ways in one process
     const bool lean = !(e && atoi(e) == 0);
     if (!lean || p->prm.kind != GT_PR || check || iters == 0 || p->iteration + 1 >= iters) return 0;
     return p->iteration + 2 == iters ? 1 : 2;
@@ -337,7 +353,7 @@ int gt_bu_maps_init(gt_program *p, hipStream_t s);   // BFS initialize(): both r
 extern "C" int gt_read_back(gt_program *p, void *dst, const void *src_dev, size_t bytes, hipStream_t s);   // (inside engine.hip's extern "C" block; not part of the ABI header)
 // Every wait of an iteration loop goes through this: a spin on the stream with a deadline (GRAPHTAP_TIMEOUT_S, else
 // GRAPHTAP_DIST_TIMEOUT_S, default 300 s; read per call). GT_ERR_TIMEOUT + a message when it passes (engine.hip)
-extern "C" int gt_stream_wait_deadline(hipStream_t s, const char *what);
+extern "C" int gt_stream_wait_deadline(hipStream_t s, const char *what, double limit_s = 0);   // limit_s <= 0: gt_wait_limit_s()
 extern "C" double gt_wait_limit_s(void);
 bool gt_frontier_list_worth(const gt_program *p, uint64_t n);   // kernels.hip
 bool gt_bfs_bottom_up_likely(const gt_program *p);   // host-side part of the bottom-up test (kernels.hip)

@@ -520,7 +520,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_d
     // the all-to-all of slice k+1 can overlap phase 1 of slice k.
     uint32_t K = 1;
     if (multi) {
-        const char *e = getenv("GRAPHTAP_X_SLICES");
+        const char *e = gt_cfg(g, "GRAPHTAP_X_SLICES");
         // Slicing is not free (engine.hip, combine_impl: +0.025 ms per step at K = 2, +0.05 ms at K = 4 on a tile-row of 8)
         // and hides (K-1)/K of the exchange: worth four slices while a rank receives tens of MB over one to three xGMI
         // links (2 or 4 ranks), two at 8 ranks (6 MB per link).
@@ -593,7 +593,7 @@ int gt_ingest(gt_graph *g, const void *edges_dev, uint64_t m, int weighted, gt_d
             // ~20 count classes, each a sparse sweep of the sender's gather over its whole segment buffer (k_pack_send: 12.6 M gathers
             // pulling ~1.6 GB of lines, 0.08 ms per step on a tile-row of 8 of R-MAT-26); the receiver gains nothing from an order among
             // columns that hold one to a few entries. Both sides derive the order from the same counts. GRAPHTAP_EXCHANGE_HUB_MIN.
-            const char *hm = getenv("GRAPHTAP_EXCHANGE_HUB_MIN");
+            const char *hm = gt_cfg(g, "GRAPHTAP_EXCHANGE_HUB_MIN");
             const uint32_t hub_min = hm ? (uint32_t)atoi(hm) : 8u;
             std::vector<uint32_t> start_me(nblk + 1, 0), start_by(nblk + 1, 0);
             for (uint32_t b = 0; b < nblk; b++) {   // b = kk * p + q, the order of the sort key

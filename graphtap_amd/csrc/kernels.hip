@@ -693,10 +693,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_tail(uint32_t *__restrict__ li
 int gt_tail_try(gt_program *p, hipStream_t s, bool *converged, uint32_t *iterations_run) {
     *converged = false; *iterations_run = 0;
     const gt_graph *g = p->g;
-    const int enabled = getenv("GRAPHTAP_TAIL_KERNEL") ? atoi(getenv("GRAPHTAP_TAIL_KERNEL")) : 1;   // 0: never
-    const uint32_t n_cap = std::min<uint32_t>(TAIL_N, getenv("GRAPHTAP_TAIL_LIST") ? (uint32_t)atoi(getenv("GRAPHTAP_TAIL_LIST")) : 4096u);   // longest list it takes
-    const uint32_t ent_cap = getenv("GRAPHTAP_TAIL_ENTRIES") ? (uint32_t)atoi(getenv("GRAPHTAP_TAIL_ENTRIES")) : (1u << 17);          // most entries of its columns
-    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    const int enabled = gt_cfg(p, "GRAPHTAP_TAIL_KERNEL") ? atoi(gt_cfg(p, "GRAPHTAP_TAIL_KERNEL")) : 1;   // 0: never
+    const uint32_t n_cap = std::min<uint32_t>(TAIL_N, gt_cfg(p, "GRAPHTAP_TAIL_LIST") ? (uint32_t)atoi(gt_cfg(p, "GRAPHTAP_TAIL_LIST")) : 4096u);   // longest list it takes
+    const uint32_t ent_cap = gt_cfg(p, "GRAPHTAP_TAIL_ENTRIES") ? (uint32_t)atoi(gt_cfg(p, "GRAPHTAP_TAIL_ENTRIES")) : (1u << 17);          // most entries of its columns
+    const char *senv = gt_cfg(p, "GRAPHTAP_SPMSPV");
     if (senv && atoi(senv) == 0) return GT_OK;   // the sparse paths are switched off: this is one
     if (!enabled || !p->fl_enabled || !p->fl_cur_valid || gt_has_exchange(g) || p->fl_cur_n == 0 || p->fl_cur_n > n_cap || !p->d_tail) return GT_OK;
     if (p->semiring != GT_MIN_U32 && p->semiring != GT_MINPLUS_U32) return GT_OK;
@@ -779,14 +779,14 @@ __global__ void k_cc_first_neighbour(const uint32_t *__restrict__ R2C, const uin
 // pass is taken after all. BFS R-MAT-26: the 0.2-ms pass over 33 M slots before the first list iteration after the bottom-up
 // steps; CC: 0.18 ms for resetting the 3.7 M slots of the previous frontier before a 13 K-vertex one.
 bool gt_list_spmspv_likely(const gt_program *p) {
-    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    const char *senv = gt_cfg(p, "GRAPHTAP_SPMSPV");
     if (gt_has_exchange(p->g) || !p->fl_enabled || !p->fl_cur_valid || (senv && atoi(senv) == 0)) return false;
     return gt_frontier_list_worth(p, p->fl_cur_n);
 }
 bool gt_cc_first_likely(const gt_program *p) {
     const gt_graph *g = p->g;
-    const char *e = getenv("GRAPHTAP_CC_FIRST");   // 0: iteration 0 sweeps like every other
-    const char *senv = getenv("GRAPHTAP_SPMSPV");  // 0: no sparse path of any kind
+    const char *e = gt_cfg(p, "GRAPHTAP_CC_FIRST");   // 0: iteration 0 sweeps like every other
+    const char *senv = gt_cfg(p, "GRAPHTAP_SPMSPV");  // 0: no sparse path of any kind
     return p->prm.kind == GT_CC && p->iteration == 0 && !p->converged && !g->flags.directed && !gt_has_exchange(g) && g->info.nnzrows != 0 && g->info.nnz_local != 0 &&
            !(e && atoi(e) == 0) && !(senv && atoi(senv) == 0);
 }
@@ -808,9 +808,9 @@ static int cc_first_iteration_try(gt_program *p, hipStream_t s, bool *done) {
 // by the full apply itself, and its pass streams. Collecting 5 M changed vertices from the flags took 0.08 ms per iteration of
 // SSSP on R-MAT-24 (+ 0.02-0.04 for looking at the list again), four times in a 3.4-ms run.
 bool gt_frontier_list_worth(const gt_program *p, uint64_t n) {
-    const char *env = getenv("GRAPHTAP_SPMSPV");
+    const char *env = gt_cfg(p, "GRAPHTAP_SPMSPV");
     if (gt_has_exchange(p->g) || (env && atoi(env) == 1)) return true;   // several ranks: the list travels as pairs; forced SpMSpV: any list
-    static const uint64_t frac0 = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
+    const uint64_t frac0 = gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION")) : 32;
     return n <= 4096 || n * 8 <= p->g->info.nnz_local / frac0;
 }
 
@@ -819,9 +819,9 @@ bool gt_frontier_list_worth(const gt_program *p, uint64_t n) {
 // rows are unreached than vertices are active and the unreached rows' columns hold few entries (counted exactly first).
 bool gt_bfs_bottom_up_likely(const gt_program *p) {
     const gt_graph *g = p->g;
-    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const char *menv = gt_cfg(p, "GRAPHTAP_BFS_BOTTOM_UP");
     const int mode = menv ? atoi(menv) : -1;   // 0 never, 1 whenever possible, unset: by size
-    const char *senv = getenv("GRAPHTAP_SPMSPV");
+    const char *senv = gt_cfg(p, "GRAPHTAP_SPMSPV");
     if (mode == 0 || (senv && atoi(senv) == 0) || !p->fl_enabled || !p->bu_rows || p->prm.kind != GT_BFS || g->flags.directed || g->info.nnzrows == 0) return false;
     const uint64_t nr = g->info.nnzrows, unreached = nr > p->bfs_settled ? nr - p->bfs_settled : 0;
     if (mode == 1 || p->last_active == ~0ull) return mode == 1;
@@ -847,7 +847,7 @@ int gt_bu_maps_init(gt_program *p, hipStream_t s) {
 // (nnzrows - vertices reached so far) and, for a frontier that is a list, the entries of its columns.
 static int bfs_bottom_up_maps_try(gt_program *p, hipStream_t s, bool *done) {
     const gt_graph *g = p->g;
-    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const char *menv = gt_cfg(p, "GRAPHTAP_BFS_BOTTOM_UP");
     const int mode = menv ? atoi(menv) : -1;
     const bool dbg = getenv("GRAPHTAP_PB_STATS") != nullptr;
     const uint64_t nr = g->info.nnzrows, nnz = g->info.nnz_local;
@@ -889,7 +889,7 @@ static int bfs_bottom_up_maps_try(gt_program *p, hipStream_t s, bool *done) {
 
 static int bfs_bottom_up_try(gt_program *p, hipStream_t s, bool *done) {
     const gt_graph *g = p->g;
-    const char *menv = getenv("GRAPHTAP_BFS_BOTTOM_UP");
+    const char *menv = gt_cfg(p, "GRAPHTAP_BFS_BOTTOM_UP");
     const int mode = menv ? atoi(menv) : -1;
     const char *eenv = getenv("GRAPHTAP_BFS_BU_EARLY");   // 0: every neighbour is looked at (A/B, tests)
     const bool early = !(eenv && atoi(eenv) == 0);
@@ -945,7 +945,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     *done = false;
     const gt_graph *g = p->g;
     if (p->semiring != GT_MIN_U32 && p->semiring != GT_MINPLUS_U32) return GT_OK;
-    const char *env = getenv("GRAPHTAP_SPMSPV");               // "0": never, "1": whenever there is a frontier, unset: by size
+    const char *env = gt_cfg(p, "GRAPHTAP_SPMSPV");               // "0": never, "1": whenever there is a frontier, unset: by size
     if (env && atoi(env) == 0) return GT_OK;
     const uint64_t nnz = g->info.nnz_local;
     if (nnz == 0) return GT_OK;
@@ -982,7 +982,7 @@ int gt_spmspv_try(gt_program *p, hipStream_t s, bool *done) {
     // active column (pb.hip), so the frontier-driven kernels only pay for small frontiers; this scan-based entry is what is left
     // when no frontier list exists (several ranks without slices, lists switched off): at most nnz / 1024 entries, and the
     // frontier is only counted when the previous apply activated <= 16 384 vertices.
-    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 1024;
+    const uint64_t frac = gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION")) : 1024;
     if (!force && h[1] > nnz / frac) return GT_OK;
     GT_REQUIRE(h[0] < 0xFFFFFFFFull && h[1] < (1ull << 40), GT_ERR_UNSUPPORTED, "frontier too large for the sparse path");
     const uint32_t nact = (uint32_t)h[0];
@@ -1051,7 +1051,7 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     if (nact == 0) { *done = true; p->fl_rows_valid = true; GT_HIP(hipMemsetAsync(p->d_fl + 2, 0, sizeof(unsigned int), s)); return GT_OK; }   // nothing is active: y keeps its minima
     if (!force) {   // counting costs a pass over the list and a round trip (0.15 ms at 8 M vertices): not for a frontier that cannot
                     // qualify -- the mid-run frontiers hold 8+ entries per vertex, only the tail ones fewer (1.3)
-        static const uint64_t frac0 = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
+        const uint64_t frac0 = gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION")) : 32;
         if ((uint64_t)nact * 8 > g->info.nnz_local / frac0) return GT_OK;
     }
     if (p->fr_cap < nact + 1) { int st = gt_spmspv_reserve(p, nact); if (st != GT_OK) return st; }
@@ -1075,7 +1075,7 @@ static int spmspv_from_list(gt_program *p, hipStream_t s, bool force, bool *done
     // From the list, with eight lanes per column, the sparse pass wins up to ~nnz/32 entries (tools/spmspv_sweep.sh on R-MAT-26:
     // 10 M entries of 1.27 M columns 0.41 against 1.49 ms, 4.7 M of 3.7 M columns 0.41 against 0.95 ms, but 102 M entries of
     // 8.1 M columns 2.1 against 1.8 ms)
-    static const uint64_t frac = getenv("GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(getenv("GRAPHTAP_SPMSPV_FRACTION")) : 32;
+    const uint64_t frac = gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION") ? (uint64_t)atoll(gt_cfg(p, "GRAPHTAP_SPMSPV_FRACTION")) : 32;
     if (!force && h[1] > g->info.nnz_local / frac) return GT_OK;   // the streaming pass does it (x is complete either way)
     GT_REQUIRE(h[1] < 0xFFFFFFFFull, GT_ERR_UNSUPPORTED, "frontier entry offsets exceed 32 bits");
     int st = gt_spmspv_run_frontier(p, nact, s);

@@ -62,8 +62,8 @@ constexpr uint32_t WS = GT_PB_SPARSE_WINDOW;   // 16384 slots per sparse window:
 // Entries per chunk. A window is one chunk unless it holds more than `ch` entries; such windows are cut by row bin (k_win_plan),
 // which leaves their runs whole, so `ch` only sets the granularity of the launch. Small graphs: the grid must
 // still be several times the 512 resident phase-1 workgroups, so `ch` shrinks until there are >= ~2048 chunks.
-static uint32_t ch_default(uint32_t nnz, uint32_t nwin) {
-    const char *e = getenv("GRAPHTAP_PB_CH");
+static uint32_t ch_default(const gt_graph *g, uint32_t nnz, uint32_t nwin) {
+    const char *e = gt_cfg(g, "GRAPHTAP_PB_CH");
     if (e) return 1u << atoi(e);
     if (nwin >= 2048) return 1u << 19;   // the windows alone give enough chunks: only the heavy windows are cut
     uint32_t ch = 1u << 14;
@@ -1096,7 +1096,7 @@ int gt_layout_build(gt_graph *g) {
     const uint32_t nc = g->info.nnzcols, nr = g->info.nnzrows;
     g->x_len = g->ncols_total;
     g->ndw = (g->ncols_total + W - 1) / W;     // identity layout: every window is a dense window
-    const char *e = getenv("GRAPHTAP_PB_HUBS");
+    const char *e = gt_cfg(g, "GRAPHTAP_PB_HUBS");
     if (gt_has_exchange(g) || nc == 0 || (e && atoi(e) == 0)) return GT_OK;
     hipStream_t s = 0;
     // Hub = a column with at least `thr` entries: its window is worth the aggregating kernel. R-MAT-26: the 1.05 M columns of
@@ -1105,7 +1105,7 @@ int gt_layout_build(gt_graph *g) {
     // Since the outputs of the plus kernels leave through the staged stores a sparsely filled dense window costs less: 12
     // instead of 24 is 393 M instead of 400 M slots on R-MAT-26 and ~3 % (PageRank 1.59 -> 1.54 ms, A/B); the weighted graphs
     // (SSSP: direct stores) keep 24, where 12 was 3-4 % slower; BFS / CC are indifferent.
-    const char *et = getenv("GRAPHTAP_PB_HUB_DEG");
+    const char *et = gt_cfg(g, "GRAPHTAP_PB_HUB_DEG");
     // Re-measured with round 3's final kernels (profiles/r03/ab_hub_threshold_final.txt, four rounds on one box): 8 or 10 instead of 12 is a
     // steady 1 % for PageRank (phase 2 -2 %: fewer slots), nothing for BFS and +1-2 % for CC on their symmetrised graphs: 8 on directed graphs.
     const uint32_t thr = et ? (uint32_t)atoi(et) : (g->info.weighted ? 24u : g->flags.directed ? 8u : 12u);
@@ -1204,7 +1204,7 @@ int gt_pb_build(gt_graph *g) {
     geom.ncls = classes ? 2u : 1u; geom.nvwin = geom.nwin * geom.ncls;
     const uint32_t nwin = geom.nvwin;   // "windows" below are virtual windows: (row class, window)
     (void)nc;
-    uint32_t ch = ch_default(nnz, geom.nwin);
+    uint32_t ch = ch_default(g, nnz, geom.nwin);
     DevBuf wcount, nsub, cbase, cutflag, cutidx, plan, srcbits_b;
     const uint32_t *srcbits = nullptr;
     if (classes) {
@@ -1614,7 +1614,8 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         // 6.16 -> 6.14, CC R-MAT-26 7.67 -> 7.50 / 7.54 -> 7.82, SSSP R-MAT-24 2.82 -> 2.92 (its four extra enqueues per pass cost more
         // than the 47 % of iteration 4 it skips). The hub windows it removes are the CHEAP part of a min pass (12 entries per
         // value-stream slot: little store traffic), and phase 2 still streams every slot of a bin that any chunk fed.
-        const bool hybrid_on = getenv("GRAPHTAP_HYBRID") && atoi(getenv("GRAPHTAP_HYBRID")) != 0;   // (read per call: the tests run both ways in one process)
+        const char *eh = gt_cfg((const gt_program *)owner, "GRAPHTAP_HYBRID");   // (`owner` of a min program's SpMV is the program)
+        const bool hybrid_on = eh && atoi(eh) != 0;   // (read per call: the tests run both ways in one process)
         if (hybrid_on && filter && pb->win_mode && pb->hy_ncand && g->info.x_slices == 1 && !gt_has_exchange(g) &&
             phases == (GT_PB_PREPARE | GT_PB_PHASE1 | GT_PB_PHASE2)) {
             WinGeom geom{}; geom.ndw = pb->ndw_; geom.dense_end = pb->dense_end_; geom.nwin = pb->nwin; geom.x_len = g->x_len; geom.ncls = 1; geom.nvwin = pb->nwin;

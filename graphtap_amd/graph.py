@@ -64,8 +64,9 @@ def read_edge_file(path, weighted):
 class Graph:
     """Graph<Weight, Integer_Type, Fractional_Type> (src/mat/graph.hpp:31-71)."""
 
-    def __init__(self, weighted=False):
+    def __init__(self, weighted=False, options=None):
         self.weighted = bool(weighted)   # the reference fixes this at compile time (-DHAS_WEIGHT)
+        self.options = options           # _lib.GraphOptions, or None: the environment variables / defaults
         self._h = None
         self.info = None
         self.flags = None
@@ -139,12 +140,17 @@ class Graph:
             rank, nranks = world()
         self.free()
         self.rank, self.nranks = rank, nranks
-        self.exchange = nranks > 1 or os.environ.get("GRAPHTAP_FORCE_EXCHANGE", "0") not in ("", "0")
+        self.exchange = nranks > 1 or (bool(self.options.force_exchange) if self.options is not None and self.options.force_exchange >= 0
+                                       else os.environ.get("GRAPHTAP_FORCE_EXCHANGE", "0") not in ("", "0"))
         self.compression_type = compression_type
         self.flags = GraphFlags(int(directed), int(transpose), int(self_loops), int(acyclic), int(parallel_edges))
         h = C.c_void_p()
-        check(lib().gt_graph_build(C.byref(h), ptr, m, on_device, int(self.weighted), int(nrows),
-                                   C.byref(self.flags), rank, nranks))
+        if self.options is not None:   # handle-level configuration (gt_graph_options) instead of the environment
+            check(lib().gt_graph_build_opt(C.byref(h), None, ptr, m, on_device, int(self.weighted), int(nrows),
+                                           C.byref(self.flags), rank, nranks, C.byref(self.options)))
+        else:
+            check(lib().gt_graph_build(C.byref(h), ptr, m, on_device, int(self.weighted), int(nrows),
+                                       C.byref(self.flags), rank, nranks))
         self._h = h
         self.info = GraphInfo()
         check(lib().gt_graph_info_get(self._h, C.byref(self.info)))

@@ -190,6 +190,12 @@ class Vertex_Program:
         check(lib().gt_program_iteration(self._handle(), C.byref(it)))
         return it.value
 
+    def set_options(self, options=None, **kw):
+        """gt_program_set_options: per-program configuration (a _lib.ProgramOptions, or its fields as keywords)."""
+        from ._lib import ProgramOptions
+        o = options if options is not None else ProgramOptions(**kw)
+        check(lib().gt_program_set_options(self._handle(), C.byref(o)))
+
     # -- initialize(), vp:443-464 / initialize(other), vp:466-501
     def initialize(self, other=None):
         eng = getattr(self, "_engine", None)

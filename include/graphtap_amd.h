@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GT_ABI_VERSION 3 /* 2: gt_exec_stats grew (round 2: five fields; round 3: allocs_in_execute), gt_dist_* and gt_spmv_cf added; 3 (round 4): GT_ERR_TIMEOUT, gt_diag_hbm_ceiling */
+#define GT_ABI_VERSION 3 /* 2: gt_exec_stats grew (round 2: five fields; round 3: allocs_in_execute), gt_dist_* and gt_spmv_cf added; 3 (round 4): GT_ERR_TIMEOUT, gt_diag_hbm_ceiling, gt_graph_options / gt_program_options */
 #define GT_INF 2147483647u /* apps/bfs.h:12 */
 
 typedef enum gt_status {
@@ -225,6 +225,44 @@ int gt_graph_build(gt_graph **out, const void *edges, uint64_t m, int edges_on_d
 typedef struct gt_dist gt_dist;
 int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_share, uint64_t m_share, int edges_on_device, int weighted,
                                uint32_t num_vertices, const gt_graph_flags *flags);
+/* ---- handle-level configuration (ABI 3) -----------------------------------
+ * Everything the environment variables of README.md choose can be chosen PER HANDLE: two graphs (or two programs) of one process
+ * may differ, and a caller need not touch its environment. A field left at its "unset" value (what gt_*_options_init writes) falls
+ * back to the environment variable named beside it, then to the built-in default. `size` = sizeof the struct as the caller compiled
+ * it (fields past it are unset). No counterpart in the reference, whose knobs are compile-time (-DHAS_WEIGHT, tiling.hpp). */
+typedef struct gt_graph_options {
+    uint32_t size;
+    int32_t spmv_variant;      /* gt_spmv_variant; -1 unset: GRAPHTAP_SPMV (edge | pb | pb_f32msg), default GT_SPMV_PB */
+    int32_t force_exchange;    /* 1 / 0; -1 unset: GRAPHTAP_FORCE_EXCHANGE (exchange layout on one rank: rehearses the N-rank driver) */
+    uint32_t x_slices;         /* K slices of the exchange; 0 unset: GRAPHTAP_X_SLICES, default 4 at 2-4 ranks, 2 beyond */
+    int32_t hubs_first;        /* 1 / 0; -1 unset: GRAPHTAP_PB_HUBS, default 1 (single rank) */
+    uint32_t hub_min_degree;   /* entries from which a column is a hub; 0 unset: GRAPHTAP_PB_HUB_DEG, default 8 / 12 / 24 */
+    uint32_t exchange_hub_min; /* the same inside a block of the exchange layout; 0 unset: GRAPHTAP_EXCHANGE_HUB_MIN, default 8 */
+    uint32_t chunk_log2;       /* log2 entries per phase-1 chunk; 0 unset: GRAPHTAP_PB_CH, default by size (<= 19) */
+    uint32_t reserved[8];
+} gt_graph_options;
+typedef struct gt_program_options {
+    uint32_t size;
+    int32_t frontier_lists;    /* 1 / 0; -1 unset: GRAPHTAP_FRONTIER_LISTS, default 1 */
+    int32_t spmspv;            /* 1 always / 0 never; -1 unset: GRAPHTAP_SPMSPV, default by size */
+    int32_t tail_kernel;       /* 1 / 0; -1 unset: GRAPHTAP_TAIL_KERNEL, default 1 */
+    int32_t bfs_bottom_up;     /* 1 always / 0 never; -1 unset: GRAPHTAP_BFS_BOTTOM_UP, default by size */
+    int32_t cc_first;          /* 1 / 0; -1 unset: GRAPHTAP_CC_FIRST, default 1 */
+    int32_t fuse_apply;        /* 1 / 0; -1 unset: GRAPHTAP_FUSE_APPLY, default 1 */
+    int32_t lean_state;        /* 1 / 0; -1 unset: GRAPHTAP_PR_LEAN_STATE, default 1 */
+    int32_t hybrid;            /* 1 / 0; -1 unset: GRAPHTAP_HYBRID, default 0 */
+    uint32_t spmspv_fraction;  /* the SpMSpV takes frontiers of up to nnz / this entries; 0 unset: GRAPHTAP_SPMSPV_FRACTION, default 32 */
+    uint32_t tail_list_max;    /* longest list the one-launch tail takes; 0 unset: GRAPHTAP_TAIL_LIST, default 4096 */
+    uint32_t tail_entries_max; /* most entries of its columns; 0 unset: GRAPHTAP_TAIL_ENTRIES, default 2^17 */
+    uint32_t reserved0;
+    double timeout_s;          /* deadline of every wait of execute(); <= 0 unset: GRAPHTAP_TIMEOUT_S, default 300 */
+    uint32_t reserved[8];
+} gt_program_options;
+void gt_graph_options_init(gt_graph_options *o);
+void gt_program_options_init(gt_program_options *o);
+/* gt_graph_build / gt_graph_build_distributed (dist != NULL) with options; opt == NULL is the plain call */
+int gt_graph_build_opt(gt_graph **out, gt_dist *dist, const void *edges, uint64_t m, int edges_on_device, int weighted,
+                       uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, const gt_graph_options *opt);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
 /* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
  * GT_SPMV_PB; GT_SPMV_PB_F32MSG / GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=pb_f32msg / edge at build time). */
@@ -249,6 +287,8 @@ int gt_graph_free(gt_graph *g);
 /* ctor, vertex_program.hpp:214-330 (stationary / gather_depends_on_apply /
  * apply_depends_on_iter are implied by `kind` exactly as the apps set them). */
 int gt_program_create(gt_program **out, gt_graph *g, const gt_program_params *params);
+/* Options of one program (see gt_program_options): before or after initialize(); they take effect from the next execute(). */
+int gt_program_set_options(gt_program *p, const gt_program_options *opt);
 /* initialize(), vp:443-464 */
 int gt_program_initialize(gt_program *p);
 /* initialize(other), vp:466-501: PageRank takes Deg's degrees where the row is non-empty */

@@ -34,7 +34,8 @@ def test_struct_layouts_match_header(tmp_path):
     from graphtap_amd import _lib
     pairs = [("gt_graph_flags", _lib.GraphFlags, "parallel_edges"), ("gt_graph_info", _lib.GraphInfo, "send_elems"),
              ("gt_tile_arrays", _lib.TileArrays, "L2G"), ("gt_exchange_plan", _lib.ExchangePlan, "recv_counts"),
-             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "reserved0")]
+             ("gt_program_params", _lib.ProgramParams, "tol"), ("gt_exec_stats", _lib.ExecStats, "reserved0"),
+             ("gt_graph_options", _lib.GraphOptions, "reserved"), ("gt_program_options", _lib.ProgramOptions, "reserved")]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "graphtap_amd.h"\nint main(void){' +
                    "".join('printf("%%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (c, c, m) for c, _, m in pairs) + "return 0;}")
@@ -45,6 +46,18 @@ def test_struct_layouts_match_header(tmp_path):
         size, off = map(int, line.split())
         assert C.sizeof(cls) == size and getattr(cls, member).offset == off, cname
     assert C.sizeof(_lib.GraphInfo) == 96 and C.sizeof(_lib.ExecStats) == 104
+
+
+def test_option_structs_start_unset():
+    """gt_graph_options_init / gt_program_options_init (no GPU needed): every field at its "unset" value, size filled in."""
+    from graphtap_amd import _lib
+    g, p = _lib.GraphOptions(), _lib.ProgramOptions()
+    assert g.size == C.sizeof(_lib.GraphOptions) and (g.spmv_variant, g.force_exchange, g.hubs_first) == (-1, -1, -1)
+    assert (g.x_slices, g.hub_min_degree, g.exchange_hub_min, g.chunk_log2) == (0, 0, 0, 0)
+    assert p.size == C.sizeof(_lib.ProgramOptions) and p.timeout_s == 0.0
+    assert all(getattr(p, f) == -1 for f in ("frontier_lists", "spmspv", "tail_kernel", "bfs_bottom_up", "cc_first", "fuse_apply", "lean_state", "hybrid"))
+    with pytest.raises(TypeError):
+        _lib.GraphOptions(no_such_field=1)
 
 
 def test_no_cpu_fallback_without_a_gpu():

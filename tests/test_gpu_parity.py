@@ -1088,6 +1088,56 @@ def test_every_wait_of_execute_has_a_deadline(gt, monkeypatch):
     P2.free(); P.free(); V.free(); G.free()
 
 
+def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatch):
+    """gt_graph_options / gt_program_options (ABI 3): what the GRAPHTAP_* environment variables choose, per handle. Two graphs of
+    one process are built with different SpMV variants, hub thresholds and chunk sizes -- no environment variable is touched -- and
+    both give the oracle's PageRank; a program-level option wins over the environment (SpMSpV forced / forbidden per program,
+    seen in its statistics); a per-program deadline makes ONE program time out while another of the same graph runs on."""
+    from graphtap_amd.rmat import rmat_edges
+    for k in ("GRAPHTAP_SPMV", "GRAPHTAP_PB_HUB_DEG", "GRAPHTAP_PB_CH", "GRAPHTAP_SPMSPV", "GRAPHTAP_TIMEOUT_S"): monkeypatch.delenv(k, raising=False)
+    scale, nv = 16, 1 << 16
+    w = rmat_edges(scale, 16, 4, weighted=True); e = np.ascontiguousarray(w[:, :2])
+    ref = O.run_app("pr", e, nv, iters=20)
+    def width(P):   # bytes of a message of this program: 4 under GT_SPMV_PB_F32MSG (fixed-count runs), else 8
+        wd = C.c_uint32(); gt._lib.check(gt._lib.lib().gt_program_x(P._handle(), None, None, C.byref(wd))); return wd.value
+    widths = []
+    for opts in (gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, hub_min_degree=64, chunk_log2=14),
+                 gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_EDGE), gt.GraphOptions(hubs_first=0), None):
+        G = gt.Graph(options=opts); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+        V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+        P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(20)
+        assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+        widths.append(width(P))
+        P.free(); V.free(); G.free()
+    assert widths == [4, 8, 8, 8], widths          # the variants really differed inside one process
+    monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")    # ... and an option wins over the environment
+    G = gt.Graph(options=gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB)); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+    V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+    P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(20)
+    assert width(P) == 8
+    # a per-program deadline: this program gives up, its sibling on the same graph does not
+    P2 = gt.PR_Program(G, True, False, False, gt._ROW_); P2.initialize(V)
+    P2.set_options(timeout_s=1e-7)
+    with pytest.raises(gt.GraphTapError, match="did not complete within"):
+        P2.execute(2000)
+    gt._lib.check(gt._lib.lib().gt_device_synchronize())
+    P.initialize(V); P.execute(20)
+    assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+    P2.free(); P.free(); V.free(); G.free()
+    monkeypatch.delenv("GRAPHTAP_SPMV")
+    # program options of a min program: the sparse path forced / forbidden per program, same labels
+    want = O.run_app("sssp", w, nv, root=3)
+    G = gt.Graph(weighted=True); G.load_edges(w, nv, nv, True, True, False, False, False, gt._2DT_, gt._TCSC_, rank=0, nranks=1)
+    seen = {}
+    for name, kw in (("never", dict(spmspv=0, tail_kernel=0)), ("always", dict(spmspv=1, tail_kernel=0)), ("hybrid", dict(hybrid=1, spmspv=0, tail_kernel=0))):
+        S = gt.SSSP_Program(G, False, True, False, gt._ROW_); S.root = 3; S.set_options(**kw); S.execute()
+        assert (S.V["distance"] == want["distance"]).all() and S.iteration == want["iterations"], name
+        seen[name] = S.stats.spmspv_iterations
+        S.free()
+    assert seen["never"] == 0 and seen["always"] > 0, seen
+    G.free(); ref["graph"].close(); want["graph"].close()
+
+
 def test_multirank_tile_rows_are_balanced(gt):
     """Contiguous id ranges of R-MAT are badly skewed (tile-row 0 of 8 would hold ~44 % of the entries); the hashed
     internal id space must give every rank a similar share of entries, rows and columns."""
