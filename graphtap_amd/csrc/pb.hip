@@ -389,9 +389,9 @@ __global__ void k_count_ends(const uint64_t *__restrict__ key64, const uint32_t 
 }
 // outputs of run s = X[pvstart[s+1]] - X[pvstart[s]] (X = exclusive scan of E), padded to a multiple of 4
 __global__ void k_run_outputs(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ X, uint32_t nrun,
-                              uint32_t *__restrict__ noutpad) {
+                              uint32_t *__restrict__ noutpad, uint32_t align) {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nrun; s += gridDim.x * blockDim.x)
-        noutpad[s] = (X[pvstart[s + 1]] - X[pvstart[s]] + 3) & ~3u;
+        noutpad[s] = (X[pvstart[s + 1]] - X[pvstart[s]] + align - 1) & ~(align - 1);
 }
 __global__ void k_static_streams(const uint64_t *__restrict__ key64, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ sid,
                                  uint64_t n, int binbits, const uint32_t *__restrict__ ccol0, const uint32_t *__restrict__ JI,
@@ -848,15 +848,23 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // scan of the per-lane counts was twenty instructions)
             const uint32_t i0 = lanes_below(E3, lanes_below(E2, lanes_below(E1, lanes_below(E0, 0u))));
             const bool head = lane != 0 && (lc[u].c[0] & HEAD) != 0;
+#ifdef GT_EXP_P1_NO_GATHER   // timing experiment (wrong results): no LDS gathers, the column offsets stand in for the messages
+            const TV v0 = (TV)(lc[u].c[0] & COLMASK), v1 = (TV)(lc[u].c[1] & COLMASK), v2 = (TV)(lc[u].c[2] & COLMASK), v3 = (TV)(lc[u].c[3] & COLMASK);
+#else
             const TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
                      v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
+#endif
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
             // a_i = value of the stretch that entry i belongs to, up to i, inside the quad
             const TV a1 = e0 ? v1 : comb(v0, v1);
             const TV a2 = e1 ? v2 : comb(a1, v2);
             const TV a3 = e2 ? v3 : comb(a2, v3);
             // what the quad leaves open for the lanes above: everything when it holds no end, else what follows its last end
+#ifdef GT_EXP_P1_NO_SCAN   // timing experiment (wrong results): no segmented scan across the lanes
+            const TV carry = e3 ? neutral : a3;
+#else
             const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
+#endif
 #if defined(GT_P1_SBURN) || defined(GT_P1_VBURN)   // experiment: extra dependent scalar / vector instructions per group (which issue port binds phase 1?)
             {
 #ifdef GT_P1_SBURN
@@ -893,6 +901,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             const uint32_t nout = (uint32_t)(__popcll((unsigned long long)E0) + __popcll((unsigned long long)E1) + __popcll((unsigned long long)E2) + __popcll((unsigned long long)E3));
             const uint32_t d0 = __builtin_amdgcn_readlane(gw[u], 0);
             const uint64_t Hb = __ballot(head);
+#ifdef GT_EXP_P1_NO_STORES   // timing experiment (wrong results): the outputs are staged and not stored
+            if (nout == 0xFFFFFFFFu)
+#endif
             for (uint32_t i = lane; i < nout; i += 64) {
                 uint32_t d = d0, j = 0;
                 for (uint64_t Hm = Hb; Hm; Hm &= Hm - 1) {
@@ -904,7 +915,15 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                     else { const uint32_t s0r = __builtin_amdgcn_readlane(gw[u], 7); D = KSTART[s0r + j] + (d0 - KSTART[s0r]); }   // delta(run s) = KSTART[s] + X[group start]
                     d = i >= S ? D : d;
                 }
+#ifdef GT_EXP_P1_SEQ_STORES   // timing experiment (wrong results): the same stores, each workgroup to ONE contiguous span of the value stream (the chunk's share)
+                {
+                    const uint32_t span0 = (uint32_t)(((uint64_t)q0c * 4u) / 3u) & ~63u;   // ~ the chunk's first slot if outputs were spread evenly (2.76 entries per slot)
+                    const uint32_t off = ((g0 + u - (q0c >> 6)) * 96u + i) ;                // ~96 outputs per group, consecutive groups -> consecutive slots
+                    st_stream(reinterpret_cast<TV *>(VALb + (size_t)((span0 + off) * (uint32_t)sizeof(TV))), (TV)st[i]);
+                }
+#else
                 st_stream(reinterpret_cast<TV *>(VALb + (size_t)((i + d) * (uint32_t)sizeof(TV))), (TV)st[i]);
+#endif
             }
         }
         g0 = gn;
@@ -915,6 +934,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 
 // ------------------------------------------------------------------ phase 2
 template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *acc, uint32_t r, T a) {
+#ifdef GT_EXP_P2_NO_ATOMICS   // timing experiment (wrong results): the stream is loaded, nothing is combined -- one plain LDS store per lane keeps the loads alive
+    if (r == 0x7FFFu && a == (T)12345) acc[r & (R - 1)] = a;
+    return;
+#endif
     if constexpr (IS_MIN) { if (a != GT_INF) atomicMin(&acc[r], a); }
     else if constexpr (sizeof(T) == 8) unsafeAtomicAdd(&acc[r], a);   // ds_add_f64
     else atomicAdd(&acc[r], a);
@@ -953,6 +976,9 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     __syncthreads();
     const uint32_t row0 = wk.bin << RB;
     const uint32_t rn = (nrows - row0 < R) ? nrows - row0 : R;
+#ifdef GT_EXP_P2_NO_FLUSH   // timing experiment (wrong results): the workgroup ends when its stream has been combined
+    return;
+#endif
     if constexpr (FUSE != 0) {
         if (wk.single) {   // complete sums of the bin's rows: apply them here (same arithmetic as k_pr_apply_msg, engine.hip)
             using TX = typename std::conditional<FUSE == 1, float, double>::type;
@@ -986,7 +1012,13 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                         epi.C_c[r] = ch;
                         act += (ch && !(epi.cf && source));
                     }
+#ifdef GT_EXP_P2_NO_XSTORE   // timing experiment (wrong results): the next messages are computed and not stored (one store per workgroup keeps the work)
+                    if (!source && nv == 1.2345e300) xo[c[u]] = (TX)(d[u] ? nv / (double)d[u] : 0.0);
+#elif defined(GT_EXP_P2_SEQ_XSTORE)   // timing experiment (wrong results): the same stores, to consecutive addresses instead of through the row -> slot map
+                    if (!source) xo[r] = (TX)(d[u] ? nv / (double)d[u] : 0.0);
+#else
                     if (!source) xo[c[u]] = (TX)(d[u] ? nv / (double)d[u] : 0.0);
+#endif
                 }
             }
             if (epi.d_active) {   // one atomic per workgroup
@@ -1329,7 +1361,10 @@ int gt_pb_build(gt_graph *g) {
     k_group_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pb->ccol0, geom.dense_end,
                                                chunk_shift, Eb.as<uint32_t>());
     PB_SCAN_EXCL(Eb.as<uint32_t>(), Xb.as<uint32_t>(), (uint64_t)np + 1);
-    k_run_outputs<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, noutpad.as<uint32_t>());
+    // k-slots of a run: a multiple of four (16-byte loads of phase 2); GRAPHTAP_PB_KALIGN = log2 of a coarser alignment (experiment:
+    // runs of different chunks -- different workgroups, mostly different XCDs -- then never share a cache line of the value stream)
+    const uint32_t kalign = gt_cfg(g, "GRAPHTAP_PB_KALIGN") ? 1u << std::max(2, std::min(8, atoi(gt_cfg(g, "GRAPHTAP_PB_KALIGN")))) : 4u;
+    k_run_outputs<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, noutpad.as<uint32_t>(), kalign);
     // k-order: runs by (bin, chunk) -- stable sort of the (chunk, bin)-ordered run list by bin
     k_iota<<<grid_for(nrun), TPB, 0, s>>>(iota.as<uint32_t>(), nrun);
     {

@@ -9,7 +9,7 @@ mkdir -p graphtap_amd/lib/variants
 obj=graphtap_amd/lib/variants/$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w "$@" -c -o $obj graphtap_amd/csrc/$file
 objs=""
-for f in engine ingest kernels pb dist tcsc_cf; do
+for f in engine ingest kernels pb dist tcsc_cf diag; do
   if [ "$f.hip" == "$file" ]; then objs="$objs $obj"; else objs="$objs graphtap_amd/lib/obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o graphtap_amd/lib/variants/$name.so $objs -ldl
