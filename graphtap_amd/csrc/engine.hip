@@ -392,6 +392,7 @@ int gt_graph_free(gt_graph *g) {
     void *ptrs[] = {g->JA, g->IA, g->A, g->JI, g->JC, g->IR, g->IJ, g->IV, g->JV, g->R2C, g->loc2glob, g->send_idx, g->xslot, g->xcol, g->XV, g->R2X, g->x_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     gt_pb_free(g->pb);
+    gt_pb_free(g->pb_wide);
     gt_tcsc_cf_free(g->cf);
     delete g;
     return GT_OK;
@@ -521,12 +522,13 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
 int gt_graph_select_spmv(gt_graph *g, int variant) {
     GT_REQUIRE(g, GT_ERR_INVALID, "null argument");
     GT_REQUIRE(variant >= GT_SPMV_EDGE && variant <= GT_SPMV_PB_F32MSG, GT_ERR_INVALID, "unknown SpMV variant %d", variant);
-    if (variant != GT_SPMV_EDGE && !g->pb) {
+    const int before = g->spmv_variant;
+    g->spmv_variant = variant;
+    if (variant != GT_SPMV_EDGE) {   // builds what this variant needs and the graph does not have yet (the wide build for GT_SPMV_PB_F32MSG)
         int st = gt_pb_build(g);
         gt_scratch_release();
-        if (st != GT_OK) return st;
+        if (st != GT_OK) { g->spmv_variant = before; return st; }
     }
-    g->spmv_variant = variant;
     return GT_OK;
 }
 
@@ -1218,7 +1220,8 @@ static int apply_launch(gt_program *p, uint32_t num_iterations, bool want_active
             int last = (num_iterations != 0) && (p->iteration + 1 == num_iterations);
             void *xm = p->xseg ? p->xseg : p->x;   // next iteration's messages of the owned columns
             uint32_t nlist = 0;
-            const uint32_t *list = fused ? gt_pb_split_bins(g, &nlist) : nullptr;   // after a fused combine: only the bins phase 2 left
+            // after a fused combine: only the bins phase 2 left -- of the build that SpMV ran on (4-byte messages: the wide one, if the graph has it)
+            const uint32_t *list = fused ? gt_pb_split_bins(g, &nlist, gt_pb_uses_wide(g, p->semiring, g->spmv_variant == GT_SPMV_PB_F32MSG && p->x_f32)) : nullptr;
             const uint64_t nwork = list ? (uint64_t)nlist << GT_PB_ROW_BIN_BITS : nr;
             if (nwork && p->x_f32)
                 k_pr_apply_msg<float><<<grid_for(nwork), TPB, 0, s>>>((double *)p->y, gt_row_slot(g), nr, p->rank_c, p->deg_c, p->C_c, (float *)xm,
@@ -1429,7 +1432,7 @@ int gt_program_execute(gt_program *p, uint32_t iters, gt_exec_stats *stats) {
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->scatter_gather_ms = t_sg; stats->combine_ms = t_cb; stats->apply_ms = t_ap;
         stats->scatter_gather_sq = q_sg; stats->combine_sq = q_cb; stats->apply_sq = q_ap; stats->phase_samples = samples;
-        stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g) : 0;
+        stats->fused_apply_rows = (fuse_apply && p->prm.kind == GT_PR && p->g->spmv_variant != GT_SPMV_EDGE) ? gt_pb_rows_single(p->g, gt_pb_uses_wide(p->g, p->semiring, p->g->spmv_variant == GT_SPMV_PB_F32MSG && p->x_f32)) : 0;
         stats->spmspv_iterations = p->spmspv_iters; stats->cf_filtered_iterations = p->cf_filtered; stats->list_iterations = p->list_iters;
         stats->allocs_in_execute = (gt_pb_val_allocs(p->g) - val_allocs0) + p->spmspv_allocs + (uint32_t)(p->ev.size() - ev0);
         stats->spmv_ms = p->ev_acc_ms; stats->spmv_launches = p->ev_acc_pairs;

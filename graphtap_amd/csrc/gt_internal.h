@@ -130,6 +130,7 @@ struct gt_graph {
     void *x_scratch = nullptr;     // [x_len] x 8 B: gt_spmv's copy of a caller's compressed-order x in slot order
     bool force_exchange = false;  // GRAPHTAP_FORCE_EXCHANGE: exchange layout on a single rank (rehearses the N-rank driver path)
     struct gt_pb *pb = nullptr;  // propagation-blocking structures (pb.hip)
+    struct gt_pb *pb_wide = nullptr;   // the same with windows of twice the width, for SpMVs with 4-byte messages (pb.hip, gt_pb_build)
     struct gt_tcsc_cf *cf = nullptr;  // the tile in TCSC_CF form, built on first use (tcsc_cf.hip)
     int spmv_variant = 1;        // gt_spmv_variant
     uint64_t serial = 0;         // unique per built graph (a freed graph's address may come back): what a communicator remembers having checked
@@ -292,9 +293,11 @@ static inline int gt_pr_state_mode(const gt_program *p, uint32_t iters, bool che
     if (!lean || p->prm.kind != GT_PR || check || iters == 0 || p->iteration + 1 >= iters) return 0;
     return p->iteration + 2 == iters ? 1 : 2;
 }
-const uint8_t *gt_pb_bin_single(const gt_graph *g);   // [row bins] 1 = one phase-2 workgroup owns the bin
-const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n);   // the bins that are NOT single (device list): the only rows the apply kernel visits after a fused combine
-uint32_t gt_pb_rows_single(const gt_graph *g);        // rows of those bins
+// `wide`: of the wide build (the one an SpMV with 4-byte PageRank messages runs on when the graph has it: gt_pb_uses_wide)
+bool gt_pb_uses_wide(const gt_graph *g, int semiring, bool f32_messages);
+const uint8_t *gt_pb_bin_single(const gt_graph *g, bool wide = false);   // [row bins] 1 = one phase-2 workgroup owns the bin
+const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n, bool wide = false);   // the bins that are NOT single (device list): the only rows the apply kernel visits after a fused combine
+uint32_t gt_pb_rows_single(const gt_graph *g, bool wide = false);        // rows of those bins
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases = 0,
                const gt_pr_epilogue *epi = nullptr, bool skip_source = false, uint32_t part_lo = 0, uint32_t part_hi = 0xFFFFFFFFu);

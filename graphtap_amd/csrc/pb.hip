@@ -88,7 +88,6 @@ constexpr uint32_t AGG_MASK = 255;
 constexpr uint16_t GEND = 0x8000;      // dense: last entry of its (group, row) stretch
 constexpr uint16_t COLMASK = 0x3FFF;
 constexpr uint16_t HEAD = 0x4000;      // first entry of a run (entry 0 of a quad only)
-constexpr uint16_t PADCOL = W;         // dense: LDS slot W holds the semiring's neutral message
 constexpr int TPB = 256;
 
 inline unsigned grid_for(uint64_t n) {
@@ -113,10 +112,12 @@ struct BinWork { uint32_t bin, k0, k1, single, c_lo, c_hi, pad0, pad1; };   // [
 // (vertices with in-edges but no out-edges, R2C == ~0u). Under TCSC_CF the reference leaves them out of every iteration but
 // the last (computation filtering, compressed_column.hpp:671-708, vp:1264-1317); here they get chunks of their own -- the
 // "virtual window" of an entry is cls * nwin + window -- which PageRank/TCSC_CF does not launch until the last iteration.
-struct WinGeom { uint32_t ndw, dense_end, nwin, x_len, ncls, nvwin; };
+// wd / ws: slots per dense / sparse window of THIS build: W / WS, or -- the WIDE build (gt_pb::wide) -- 2 W / 2 WS: a wide window is a
+// pair of consecutive narrow ones (the layout of x is the same for both builds), its neutral slot sits at LDS index 2 W.
+struct WinGeom { uint32_t ndw, dense_end, nwin, x_len, ncls, nvwin, wd = GT_PB_WINDOW, ws = GT_PB_SPARSE_WINDOW; };
 __device__ __forceinline__ uint32_t row_class(const uint32_t *__restrict__ srcbits, uint32_t r) { return srcbits ? (srcbits[r >> 5] >> (r & 31)) & 1u : 0u; }
-__host__ __device__ inline uint32_t win_of(const WinGeom &g, uint32_t slot) { return slot < g.dense_end ? slot / W : g.ndw + (slot - g.dense_end) / WS; }
-__host__ __device__ inline uint32_t win_col0(const WinGeom &g, uint32_t q) { return q < g.ndw ? q * W : g.dense_end + (q - g.ndw) * WS; }
+__host__ __device__ inline uint32_t win_of(const WinGeom &g, uint32_t slot) { return slot < g.dense_end ? slot / g.wd : g.ndw + (slot - g.dense_end) / g.ws; }
+__host__ __device__ inline uint32_t win_col0(const WinGeom &g, uint32_t q) { return q < g.ndw ? q * g.wd : g.dense_end + (q - g.ndw) * g.ws; }
 __device__ __forceinline__ uint32_t slot_of(const uint32_t *__restrict__ xslot, uint32_t c) { return xslot ? xslot[c] : c; }
 
 // ------------------------------------------------------------------ layout kernels (gt_layout_build)
@@ -350,12 +351,12 @@ __global__ void k_chunk_ranges(const uint32_t *__restrict__ runkey, uint32_t nru
 // per chunk: the pads' defaults. Sparse chunks: every padded position is an output (E = 1) and pads read column 0 of the window;
 // dense chunks: pads read the neutral slot PADCOL and end nothing.
 __global__ void k_chunk_defaults(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1, const uint32_t *__restrict__ ccol0, uint32_t dense_end,
-                                 uint32_t *__restrict__ E, uint16_t *__restrict__ LCOL) {
+                                 uint32_t *__restrict__ E, uint16_t *__restrict__ LCOL, uint16_t padcol) {
     const uint32_t c = blockIdx.x;
     const bool sparse = ccol0[c] >= dense_end;
     for (uint32_t pv = cv0[c] + threadIdx.x; pv < cv1[c]; pv += blockDim.x) {
         if (E) E[pv] = sparse ? 1u : 0u;
-        if (LCOL) LCOL[pv] = sparse ? (uint16_t)0 : PADCOL;
+        if (LCOL) LCOL[pv] = sparse ? (uint16_t)0 : padcol;
     }
 }
 // E[pv] = 1 when the entry at padded v-position pv ends an output. Dense chunks: the last entry of a maximal
@@ -398,11 +399,11 @@ __global__ void k_static_streams(const uint64_t *__restrict__ key64, const uint3
                                  const uint32_t *__restrict__ xslot, const uint32_t *__restrict__ A, const uint32_t *__restrict__ vstart,
                                  const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ E,
                                  const uint32_t *__restrict__ X, uint32_t dense_end, uint16_t *__restrict__ LCOL, uint16_t *__restrict__ LROW,
-                                 void *__restrict__ WT, int wt_bytes) {
+                                 void *__restrict__ WT, int wt_bytes, uint16_t head_flag) {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t e = idx[v], c = (uint32_t)(key64[v] >> (RB + binbits)), s = sid[v] - 1, o = (uint32_t)v - vstart[s];
         const uint32_t pv = pvstart[s] + o, ge = E[pv];
-        LCOL[pv] = (uint16_t)((slot_of(xslot, JI[e]) - ccol0[c]) | ((ge && ccol0[c] < dense_end) ? GEND : 0) | (o == 0 ? HEAD : 0));
+        LCOL[pv] = (uint16_t)((slot_of(xslot, JI[e]) - ccol0[c]) | ((ge && ccol0[c] < dense_end) ? GEND : 0) | (o == 0 ? head_flag : 0));   // (the wide build has no bit left for HEAD: its heads are a mask in the group record)
         if (ge) LROW[pkstart[s] + (X[pv] - X[pvstart[s]])] = (uint16_t)(key64[v] & (R - 1));
         if (WT) { if (wt_bytes == 1) ((uint8_t *)WT)[pv] = (uint8_t)A[e]; else if (wt_bytes == 2) ((uint16_t *)WT)[pv] = (uint16_t)A[e]; else ((uint32_t *)WT)[pv] = A[e]; }
     }
@@ -424,6 +425,28 @@ __global__ void k_group_table(const uint32_t *__restrict__ pvstart, const uint32
         r.s = s0; r.k0 = pkstart[s0] + (X[pv] - X[pvstart[s0]]);
         for (int i = 0; i < 6; i++) r.k[i] = (s0 + 1 + i < nrun) ? pkstart[s0 + 1 + i] - X[pvstart[s0 + 1 + i]] + X[pv] : 0;
         G[g] = r;
+    }
+}
+
+// The WIDE build's record: dword 0 = k0, 1..4 = the constants of the first FOUR run heads, 5 = the run the group starts in, 6 / 7 = the
+// mask of the lanes (quads) whose first entry begins a run -- LCOL has no bit left for it (15 column bits + the end bit)
+__global__ void k_group_table_wide(const uint32_t *__restrict__ pvstart, const uint32_t *__restrict__ pkstart, const uint32_t *__restrict__ X,
+                                   uint32_t nrun, uint32_t np, GroupRec *__restrict__ G) {
+    const uint64_t ngroups = ((uint64_t)np + 255) / 256;
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t pv = (uint32_t)(g * 256);
+        uint32_t lo = 0, hi = nrun;
+        while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (pvstart[mid] <= pv) lo = mid + 1; else hi = mid; }
+        const uint32_t s0 = lo - 1;
+        uint32_t w[8];
+        w[0] = pkstart[s0] + (X[pv] - X[pvstart[s0]]);
+        for (int i = 0; i < 4; i++) w[1 + i] = (s0 + 1 + i < nrun) ? pkstart[s0 + 1 + i] - X[pvstart[s0 + 1 + i]] + X[pv] : 0;
+        w[5] = s0;
+        uint64_t hm = 0;
+        for (uint32_t r = s0 + 1; r < nrun && pvstart[r] < pv + 256u; r++) hm |= 1ull << ((pvstart[r] - pv) >> 2);   // runs start at multiples of four padded entries
+        w[6] = (uint32_t)hm; w[7] = (uint32_t)(hm >> 32);
+        GroupRec rec; rec.k0 = w[0]; for (int i = 0; i < 6; i++) rec.k[i] = w[1 + i]; rec.s = w[7];
+        G[g] = rec;
     }
 }
 
@@ -702,6 +725,26 @@ __device__ __forceinline__ uint32_t run_delta(uint32_t lane, bool head, uint32_t
     return delta;
 }
 
+// the same for the WIDE build's group record: the head lanes are a mask (dwords 6, 7), four inline constants (dwords 1..4), the
+// group's first run in dword 5
+__device__ __forceinline__ uint32_t run_delta_wide(uint32_t lane, uint64_t Hb, uint32_t gw, const uint32_t *__restrict__ KSTART) {
+    const uint32_t nh = __builtin_amdgcn_mbcnt_hi((uint32_t)(Hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Hb, 0)) + (uint32_t)((Hb >> lane) & 1ull);   // run heads at or before this lane
+    uint32_t delta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nh < 5 ? nh : 0u) << 2), (int)gw);
+    if (__popcll((unsigned long long)Hb) >= 5) {
+        const uint32_t s0 = __builtin_amdgcn_readlane(gw, 5);
+        const uint32_t xg = __builtin_amdgcn_readlane(gw, 0) - KSTART[s0];
+        uint64_t Hm = Hb;
+        for (int i = 0; i < 4; i++) Hm &= Hm - 1;
+        for (uint32_t i = 5; Hm; i++) {
+            const uint32_t hlane = (uint32_t)__ffsll((unsigned long long)Hm) - 1;
+            Hm &= Hm - 1;
+            const uint32_t ks = KSTART[s0 + i] + xg;
+            if (lane >= hlane) delta = ks;
+        }
+    }
+    return delta;
+}
+
 // ---- wave-wide DPP scans (no LDS): lanes are the 64 quads of a 256-entry group, in order
 // source lane = lane - d inside a row of 16 (d = 1, 2, 4, 8), lane 15 of the previous row (0x142) / lane 31 (0x143) for the
 // row-crossing steps; lanes without a source read `fill`
@@ -755,7 +798,7 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m, uint32_t acc) {   //
 // float atomic costs 192+ cycles per wave instruction, and the conflict-ridden f64 ones kept the LDS 73 % busy,
 // tools/lds_atomic_bench.hip); every lane then stores its outputs itself -- the k-slots of a wave's
 // outputs are consecutive, so the 4 predicated stores of a group fill the same few cache lines.
-template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy>
+template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy, bool WIDE = false>
 __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__restrict__ cv0, const uint32_t *__restrict__ cv1,
                                                            const uint32_t *__restrict__ ccol0, uint32_t ncols,
                                                            const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
@@ -764,7 +807,12 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end,
                                                            const uint8_t *__restrict__ win_mode) {
     static_assert(W + 1 == WS, "dense and sparse chunks share one LDS window");
-    __shared__ TV xwin[WS];
+    // the WIDE build (gt_pb::wide): windows of 2 W / 2 WS slots, 15 column bits, run heads as a mask in the group record
+    constexpr uint32_t WIN = WIDE ? 2 * WS : WS, WD = WIDE ? 2 * W : W;
+    constexpr uint16_t CM = WIDE ? (uint16_t)0x7FFF : COLMASK;
+    constexpr uint32_t NHI = WIDE ? 5u : 7u, SIDX = WIDE ? 5u : 7u;   // inline run constants: heads 1 .. NHI - 1; the dword that holds the group's first run
+    static_assert(!WIDE || sizeof(TV) == 4, "the wide window is 128 KiB of 4-byte messages");
+    __shared__ TV xwin[WIN];
     // the outputs of a wave's 256-entry group, dense, before they leave in coalesced stores: four predicated dword stores per lane
     // straight to VAL (each covering a strided subset of the group's ~1 KiB of slots) were bound by the write REQUESTS they
     // make, not by bytes or instructions -- a second DPP scan added to the kernel cost nothing, staging the outputs through
@@ -785,11 +833,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         // hybrid pass (pb_run): a window whose few active columns went to the column-driven SpMSpV -- or that has none -- is left out
         // here without even staging it; its value-stream slots keep older messages of the same program (y is a running min)
         if (win_mode) {
-            const uint32_t q = sparse ? dense_end / W + (col0 - dense_end) / WS : col0 / W;
+            const uint32_t q = sparse ? (dense_end + WD - 1) / WD + (col0 - dense_end) / WIN : col0 / WD;
             if (win_mode[q] != 0) { if (threadIdx.x == 0 && chunk_active) chunk_active[c] = 0u; return; }
         }
     }
-    const uint32_t wlim = sparse ? WS : W;
+    const uint32_t wlim = sparse ? WIN : WD;
     const uint32_t wn = (ncols - col0 < wlim) ? ncols - col0 : wlim;
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     const uint32_t lane = threadIdx.x & 63;
@@ -799,11 +847,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // fetched 48 KiB of its entry stream
     constexpr bool PREFETCH = !IS_MIN;
     if constexpr (!PREFETCH) {
-        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
+        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WIN>(xwin, x, col0, wn, chunk_active, c)) return;
         __syncthreads();
     }
     constexpr uint32_t NW = P1_THREADS / 64;
-    constexpr int U = 4;   // 256-entry groups in flight per wave
+    constexpr int U = 4;   // 256-entry groups in flight per wave (the wide build, one workgroup per CU: 4, 6 and 8 run alike)
     const uint32_t gend = q1c >> 6;   // chunk ranges are multiples of 256 entries = 64 quads (k_align_chunks)
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
     char *__restrict__ VALb = reinterpret_cast<char *>(VAL);
@@ -823,20 +871,25 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     uint32_t g0 = (q0c >> 6) + wave * U;
     if (g0 < gend) issue_loads(g0, lc, gw, w);
     if constexpr (PREFETCH) {
-        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WS>(xwin, x, col0, wn, chunk_active, c)) return;
+        if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WIN>(xwin, x, col0, wn, chunk_active, c)) return;
         __syncthreads();
     }
     while (g0 < gend) {
         const uint32_t gn = g0 + NW * U;
         if (gn < gend) issue_loads(gn, nlc, ngw, nw);
+        // (Round 4, wide build: gathering the messages of all the trip's groups first, and scanning the carries of all of them in one batch
+        // -- N dependency chains side by side instead of one after the other -- were both built and measured: nothing / +6 % in phase 1,
+        // profiles/r04/ab_wide_windows.txt. The 0.13 ms its scan costs in the open at 4 waves per SIMD is issue throughput, not latency.)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (g0 + u >= gend) break;
             if (sparse) {   // one output per entry, its k-slot is its position: four values per lane, one 16-byte store
-                const uint32_t delta = run_delta(lane, lane != 0 && (lc[u].c[0] & HEAD) != 0, gw[u], KSTART);
+                uint32_t delta;
+                if constexpr (WIDE) delta = run_delta_wide(lane, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(gw[u], 7) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(gw[u], 6)   /* (readlane returns int: no sign extension into the upper half) */, gw[u], KSTART);
+                else delta = run_delta(lane, lane != 0 && (lc[u].c[0] & HEAD) != 0, gw[u], KSTART);
                 V4<TV> o;
 #pragma unroll
-                for (int j = 0; j < 4; j++) o.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & COLMASK], w[u].w[j]);
+                for (int j = 0; j < 4; j++) o.a[j] = Msg<T, TV>::val(xwin[lc[u].c[j] & CM], w[u].w[j]);
                 st_stream(reinterpret_cast<V4<TV> *>(VAL + (lane * 4 + delta)), o);   // runs start at multiples of four slots in both orders
                 continue;
             }
@@ -847,12 +900,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // dense index of the quad's first output inside the group = the ends in the lanes below (four mbcnt pairs; the DPP prefix
             // scan of the per-lane counts was twenty instructions)
             const uint32_t i0 = lanes_below(E3, lanes_below(E2, lanes_below(E1, lanes_below(E0, 0u))));
-            const bool head = lane != 0 && (lc[u].c[0] & HEAD) != 0;
+            uint64_t HbG = 0;   // the WIDE build: the head lanes come off the group record
+            if constexpr (WIDE) HbG = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(gw[u], 7) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(gw[u], 6)   /* (readlane returns int: no sign extension into the upper half) */;
+            const bool head = WIDE ? ((HbG >> lane) & 1ull) != 0 : (lane != 0 && (lc[u].c[0] & HEAD) != 0);
 #ifdef GT_EXP_P1_NO_GATHER   // timing experiment (wrong results): no LDS gathers, the column offsets stand in for the messages
-            const TV v0 = (TV)(lc[u].c[0] & COLMASK), v1 = (TV)(lc[u].c[1] & COLMASK), v2 = (TV)(lc[u].c[2] & COLMASK), v3 = (TV)(lc[u].c[3] & COLMASK);
+            const TV v0 = (TV)(lc[u].c[0] & CM), v1 = (TV)(lc[u].c[1] & CM), v2 = (TV)(lc[u].c[2] & CM), v3 = (TV)(lc[u].c[3] & CM);
 #else
-            const TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & COLMASK], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & COLMASK], w[u].w[1]),
-                     v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & COLMASK], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & COLMASK], w[u].w[3]);
+            const TV v0 = Msg<T, TV>::val(xwin[lc[u].c[0] & CM], w[u].w[0]), v1 = Msg<T, TV>::val(xwin[lc[u].c[1] & CM], w[u].w[1]),
+                     v2 = Msg<T, TV>::val(xwin[lc[u].c[2] & CM], w[u].w[2]), v3 = Msg<T, TV>::val(xwin[lc[u].c[3] & CM], w[u].w[3]);
 #endif
             auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
             // a_i = value of the stretch that entry i belongs to, up to i, inside the quad
@@ -883,7 +938,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #endif
             // the quad's first end also closes what the lanes below left open
             if constexpr (!STAGED) {   // every lane stores its outputs itself: the k-slots of a wave's outputs are consecutive
-                const uint32_t k0 = i0 + run_delta(lane, head, gw[u], KSTART);   // + the constant of the lane's run
+                const uint32_t k0 = i0 + (WIDE ? run_delta_wide(lane, HbG, gw[u], KSTART) : run_delta(lane, head, gw[u], KSTART));   // + the constant of the lane's run
                 if (e0) st_stream(reinterpret_cast<TV *>(VALb + (size_t)(k0 * (uint32_t)sizeof(TV))), comb(carry, v0));
                 if (e1) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n0) * (uint32_t)sizeof(TV))), n0 ? a1 : comb(carry, a1));
                 if (e2) st_stream(reinterpret_cast<TV *>(VALb + (size_t)((k0 + n1) * (uint32_t)sizeof(TV))), n1 ? a2 : comb(carry, a2));
@@ -900,7 +955,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // of its j-th head (lane j of gw holds dword j), KSTART for heads beyond the sixth.
             const uint32_t nout = (uint32_t)(__popcll((unsigned long long)E0) + __popcll((unsigned long long)E1) + __popcll((unsigned long long)E2) + __popcll((unsigned long long)E3));
             const uint32_t d0 = __builtin_amdgcn_readlane(gw[u], 0);
-            const uint64_t Hb = __ballot(head);
+            const uint64_t Hb = WIDE ? HbG : __ballot(head);
 #ifdef GT_EXP_P1_NO_STORES   // timing experiment (wrong results): the outputs are staged and not stored
             if (nout == 0xFFFFFFFFu)
 #endif
@@ -911,8 +966,8 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                     j++;
                     const uint32_t S = __builtin_amdgcn_readlane(i0, hl);
                     uint32_t D;
-                    if (j < 7) D = __builtin_amdgcn_readlane(gw[u], j);
-                    else { const uint32_t s0r = __builtin_amdgcn_readlane(gw[u], 7); D = KSTART[s0r + j] + (d0 - KSTART[s0r]); }   // delta(run s) = KSTART[s] + X[group start]
+                    if (j < NHI) D = __builtin_amdgcn_readlane(gw[u], j);
+                    else { const uint32_t s0r = __builtin_amdgcn_readlane(gw[u], SIDX); D = KSTART[s0r + j] + (d0 - KSTART[s0r]); }   // delta(run s) = KSTART[s] + X[group start]
                     d = i >= S ? D : d;
                 }
 #ifdef GT_EXP_P1_SEQ_STORES   // timing experiment (wrong results): the same stores, each workgroup to ONE contiguous span of the value stream (the chunk's share)
@@ -1052,6 +1107,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
 }  // namespace
 
 struct gt_pb {
+    bool wide = false;   // the WIDE build: windows of 2 W / 2 WS slots (128 KiB of 4-byte messages in LDS, one phase-1 workgroup per CU): ~12 % fewer value-stream slots
     uint32_t nbins = 0, nchunks = 0, nwork = 0, nnz = 0;
     uint32_t ndense = 0;       // graphs with an exchange layout (one class, K slices): chunks [0, ndense) are dense (all of them)
     // chunk ranges by (row class, kind): [b[0], b[1]) regular rows / dense windows, [b[1], b[2]) regular / sparse,
@@ -1210,16 +1266,30 @@ int gt_layout_build(gt_graph *g) {
         PB_HIP(hipStreamSynchronize(s));                                                            \
     } while (0)
 
+static int pb_build_impl(gt_graph *g, bool wide, gt_pb **out);
 int gt_pb_build(gt_graph *g) {
+    if (!g->pb) { gt_pb *pb = nullptr; int st = pb_build_impl(g, false, &pb); if (st != GT_OK) return st; g->pb = pb; }
+    // The WIDE build beside it, for the 4-byte-message PageRank (GT_SPMV_PB_F32MSG) on one rank: windows of 32 766 / 32 768 slots --
+    // pairs of the narrow ones, the layout of x is shared -- hold twice the columns per (window, row) pair: ~12 % fewer value-stream
+    // slots (4 B written + 4 B read + 2 B of row id each). 128 KiB of LDS: one phase-1 workgroup per CU; f64 messages (converge mode,
+    // gt_spmv) keep the narrow build (an f64 window of that width would be 256 KiB). GRAPHTAP_PB_WIDE=0 / 1: never / for every graph
+    // without an exchange layout.
+    const char *ew = gt_cfg(g, "GRAPHTAP_PB_WIDE");
+    const bool want = ew ? atoi(ew) != 0 : g->spmv_variant == GT_SPMV_PB_F32MSG;
+    if (want && !g->pb_wide && !gt_has_exchange(g) && g->info.nnz_local) { gt_pb *pb = nullptr; int st = pb_build_impl(g, true, &pb); if (st != GT_OK) return st; g->pb_wide = pb; }
+    return GT_OK;
+}
+static int pb_build_impl(gt_graph *g, bool wide, gt_pb **out) {
     const uint32_t nnz = (uint32_t)g->info.nnz_local, nc = g->info.nnzcols, nr = g->info.nnzrows;
     gt_pb *pb = new gt_pb();
+    pb->wide = wide;
     pb->nnz = nnz;
     pb->nbins = std::max<uint32_t>(1, (nr + R - 1) / R);
-    g->pb = nullptr;
+    *out = nullptr;
     if (nnz == 0) {   // a tile-row without entries: nothing to stream, but the K (empty) parts of phase 2 exist like everywhere else
         const uint32_t KP = gt_has_exchange(g) ? std::max<uint32_t>(g->info.x_slices, 1) : 1;
         pb->work_part.assign(KP + 1, 0); pb->split_part.assign(KP + 1, 0);
-        g->pb = pb; return GT_OK;
+        *out = pb; return GT_OK;
     }
     hipStream_t s = 0;
     int binbits = 1;
@@ -1229,14 +1299,17 @@ int gt_pb_build(gt_graph *g) {
     // index are the ncols_total columns of JA (compressed ids; the needed columns on a graph with an exchange layout).
     const uint32_t ncols = g->ncols_total;
     WinGeom geom;
-    geom.ndw = g->ndw; geom.dense_end = g->ndw * W; geom.x_len = g->x_len;
-    geom.nwin = g->ndw + (g->x_len > geom.dense_end ? (g->x_len - geom.dense_end + WS - 1) / WS : 0u);
+    const bool wgeom = wide;
+    geom.wd = wgeom ? 2 * W : W; geom.ws = wgeom ? 2 * WS : WS;   // (the wide build: pairs of the layout's windows; an odd last dense window stays single)
+    geom.ndw = wgeom ? (g->ndw + 1) / 2 : g->ndw; geom.dense_end = g->ndw * W; geom.x_len = g->x_len;
+    geom.nwin = geom.ndw + (g->x_len > geom.dense_end ? (g->x_len - geom.dense_end + geom.ws - 1) / geom.ws : 0u);
     // row classes: source rows apart (see WinGeom) unless the graph has an exchange layout (K slices of chunks in column order)
     const bool classes = !gt_has_exchange(g) && nr > 0 && !(getenv("GRAPHTAP_PB_CLASSES") && atoi(getenv("GRAPHTAP_PB_CLASSES")) == 0);
     geom.ncls = classes ? 2u : 1u; geom.nvwin = geom.nwin * geom.ncls;
     const uint32_t nwin = geom.nvwin;   // "windows" below are virtual windows: (row class, window)
     (void)nc;
     uint32_t ch = ch_default(g, nnz, geom.nwin);
+    if (wide && !gt_cfg(g, "GRAPHTAP_PB_CH") && ch >= (1u << 19)) ch <<= 1;   // a wide window costs twice the staging: twice the entries behind each
     DevBuf wcount, nsub, cbase, cutflag, cutidx, plan, srcbits_b;
     const uint32_t *srcbits = nullptr;
     if (classes) {
@@ -1346,6 +1419,7 @@ int gt_pb_build(gt_graph *g) {
         PB_HIP(hipMemcpy(hl.data(), len.p, (uint64_t)nrun * 4, hipMemcpyDeviceToHost));
         uint64_t hist[33] = {0}, cnt[33] = {0};
         for (uint32_t l : hl) { int b = 0; while ((1u << (b + 1)) <= l) b++; hist[b] += l; cnt[b]++; }
+        fprintf(stderr, "[pb] %s build (windows of %u / %u slots)\n", wide ? "WIDE" : "narrow", geom.wd, geom.ws);
         fprintf(stderr, "[pb] nnz=%u padded=%u (+%.2f%%) nbins=%u windows=%u (%u dense) chunks=%u (regular rows: %u dense + %u sparse, source rows: %u + %u) runs=%u mean run=%.1f\n", nnz, np,
                 100.0 * (np - nnz) / nnz, pb->nbins, geom.nwin, geom.ndw, nchunks, pb->bound[1] - pb->bound[0], pb->bound[2] - pb->bound[1],
                 pb->bound[3] - pb->bound[2], pb->bound[4] - pb->bound[3], nrun, (double)nnz / nrun);
@@ -1357,7 +1431,7 @@ int gt_pb_build(gt_graph *g) {
     DevBuf Eb, Xb, noutpad;
     PB_ALLOC(Eb, ((uint64_t)np + 1) * 4); PB_ALLOC(Xb, ((uint64_t)np + 1) * 4); PB_ALLOC(noutpad, (uint64_t)(nrun + 1) * 4);
     PB_HIP(hipMemsetAsync(Eb.p, 0, ((uint64_t)np + 1) * 4, s));
-    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, Eb.as<uint32_t>(), nullptr);   // sparse: pads are outputs too
+    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, Eb.as<uint32_t>(), nullptr, (uint16_t)geom.wd);   // sparse: pads are outputs too
     k_group_ends<<<grid_for(nnz), TPB, 0, s>>>(skey64, sid, nnz, vstart.as<uint32_t>(), len.as<uint32_t>(), pvstart.as<uint32_t>(), pb->ccol0, geom.dense_end,
                                                chunk_shift, Eb.as<uint32_t>());
     PB_SCAN_EXCL(Eb.as<uint32_t>(), Xb.as<uint32_t>(), (uint64_t)np + 1);
@@ -1394,7 +1468,7 @@ int gt_pb_build(gt_graph *g) {
             fprintf(stderr, "[pb] dense chunks, stretches of up to %u consecutive entries: %llu outputs\n", mask + 1, c);
         }
     }
-    if (stats) {
+    if (stats && !wide) {
         // Where the value-stream slots are: by WINDOW RANK (dense windows are in descending column-degree order, so the window index
         // is the rank) and by how heavy the row bin is. VERDICT round 3 asked for this table before any scheme that keeps the
         // heaviest windows' partial sums off HBM: such a scheme saves 10 B per slot of the windows it fuses (4 written + 4 read
@@ -1462,7 +1536,7 @@ int gt_pb_build(gt_graph *g) {
     PB_MALLOC(pb->LCOL, (uint64_t)np * 2); PB_MALLOC(pb->LROW, (uint64_t)std::max(nout, 4u) * 2);
     PB_MALLOC(pb->G, ngroups * sizeof(GroupRec));
     PB_MALLOC(pb->KSTART, (uint64_t)(nrun + 64) * 4);
-    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, nullptr, pb->LCOL);
+    k_chunk_defaults<<<nchunks, TPB, 0, s>>>(pb->cv0, pb->cv1, pb->ccol0, geom.dense_end, nullptr, pb->LCOL, (uint16_t)geom.wd);
     k_fill_t<uint16_t><<<grid_for(std::max(nout, 4u)), TPB, 0, s>>>(pb->LROW, std::max(nout, 4u), (uint16_t)R);
     if (g->A) {   // weights travel in the narrowest type that holds the largest one (the reference's converter draws 1..128)
         DevBuf mx; PB_ALLOC(mx, 4); PB_HIP(hipMemsetAsync(mx.p, 0, 4, s));
@@ -1473,8 +1547,9 @@ int gt_pb_build(gt_graph *g) {
     }
     k_static_streams<<<grid_for(nnz), TPB, 0, s>>>(skey64, sidx, sid, nnz, binbits, pb->ccol0, g->JI, g->xslot, g->A, vstart.as<uint32_t>(),
                                                    pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Eb.as<uint32_t>(), Xb.as<uint32_t>(), geom.dense_end,
-                                                   pb->LCOL, pb->LROW, pb->WT, pb->wt_bytes);
-    k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
+                                                   pb->LCOL, pb->LROW, pb->WT, pb->wt_bytes, wide ? (uint16_t)0 : HEAD);
+    if (wide) k_group_table_wide<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
+    else k_group_table<<<grid_for(ngroups), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, np, (GroupRec *)pb->G);
     PB_HIP(hipMemsetAsync(pb->KSTART, 0, (uint64_t)(nrun + 64) * 4, s));
     k_kstart<<<grid_for(nrun), TPB, 0, s>>>(pvstart.as<uint32_t>(), pkstart.as<uint32_t>(), Xb.as<uint32_t>(), nrun, pb->KSTART);
     // phase-2 work list (host: nbins is small)
@@ -1577,7 +1652,7 @@ int gt_pb_build(gt_graph *g) {
         PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
         PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
     }
-    {   // window statistics for the min programs' hybrid pass (cheap: a few MB)
+    if (!wide) {   // window statistics for the min programs' hybrid pass (cheap: a few MB)
         pb->nwin = geom.nwin; pb->ndw_ = geom.ndw; pb->dense_end_ = geom.dense_end;
         PB_MALLOC(pb->win_entries, (uint64_t)geom.nwin * 4); PB_MALLOC(pb->win_act, (uint64_t)geom.nwin * 8); PB_MALLOC(pb->xdeg, (uint64_t)std::max(g->x_len, 1u) * 4);
         k_win_total<<<grid_for(geom.nwin), TPB, 0, s>>>(wcount.as<uint32_t>(), geom.nwin, geom.ncls, pb->win_entries);
@@ -1585,7 +1660,7 @@ int gt_pb_build(gt_graph *g) {
     }
     PB_HIP(hipStreamSynchronize(s));
     PB_HIP(hipGetLastError());
-    g->pb = pb;
+    *out = pb;
     return GT_OK;
 }
 
@@ -1617,7 +1692,7 @@ int gt_pb_window_activity_report(const gt_graph *g, const void *x, hipStream_t s
     return GT_OK;
 }
 
-template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy = uint32_t>
+template <class T, class TV, class TX, bool WEIGHTED, bool IS_MIN, class WTy = uint32_t, bool WIDE = false>
 static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s, const void *owner, uint64_t epoch,
                   uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source, uint32_t part_lo, uint32_t part_hi) {
     // Activity filtering needs VAL to belong to one program between two of its initialize() calls (see stage_window).
@@ -1668,7 +1743,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
         auto scatter = [&](uint32_t c0, uint32_t c1) {
             if (c1 > c0)
-                k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy><<<c1 - c0, P1_THREADS, 0, s>>>(
+                k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<c1 - c0, P1_THREADS, 0, s>>>(
                     pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
                     (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W, win_mode);
         };
@@ -1708,7 +1783,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
 extern "C" int gt_graph_phase_times(gt_graph *g, double *phase1_ms, double *phase2_ms, uint32_t *spmvs, int reset) {
     GT_REQUIRE(g && phase1_ms && phase2_ms && spmvs, GT_ERR_INVALID, "null argument");
     *phase1_ms = *phase2_ms = 0; *spmvs = 0;
-    gt_pb *pb = g->pb;
+    gt_pb *pb = (g->pb_wide && g->pb_wide->pt_used) ? g->pb_wide : g->pb;   // the build the recorded SpMVs ran on
     if (!pb) return GT_OK;
     GT_HIP(hipDeviceSynchronize());
     for (size_t i = 0; i + 2 < pb->pt_used; i += 3) {
@@ -1724,8 +1799,7 @@ extern "C" int gt_graph_phase_times(gt_graph *g, double *phase1_ms, double *phas
 // The value stream is allocated (and touched once) where programs are initialized, never inside the iteration loop: a
 // multi-GB hipMalloc stalls for seconds now and then on this pool, and the first streaming pass of a min program -- BFS's
 // iteration 1, iteration 0 takes the SpMSpV -- used to pay for it inside execute().
-int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s) {
-    gt_pb *pb = g->pb;
+static int pb_reserve_val(gt_pb *pb, uint32_t bytes_per_slot, hipStream_t s) {
     if (!pb || pb->nnz == 0 || pb->val_cap >= bytes_per_slot) return GT_OK;
     const auto t0 = std::chrono::steady_clock::now();
     if (pb->VAL) (void)hipFree(pb->VAL);   // (a long-lived buffer: not from the build's scratch pool)
@@ -1736,15 +1810,27 @@ int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s)
     pb->val_cap = bytes_per_slot; pb->val_allocs++;
     if (getenv("GRAPHTAP_PB_STATS")) {
         GT_HIP(hipStreamSynchronize(s));
-        fprintf(stderr, "[build] value stream: %.2f GB (%u B x %u slots) allocated and touched in %.1f ms\n", bytes / 1e9, bytes_per_slot, pb->nout,
+        fprintf(stderr, "[build] value stream%s: %.2f GB (%u B x %u slots) allocated and touched in %.1f ms\n", pb->wide ? " (wide build)" : "", bytes / 1e9, bytes_per_slot, pb->nout,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     return GT_OK;
 }
-uint32_t gt_pb_val_allocs(const gt_graph *g) { return g->pb ? g->pb->val_allocs : 0; }
+// both builds: the narrow one at the width asked for, the wide one (4-byte messages only) at 4
+int gt_pb_reserve_val(const gt_graph *g, uint32_t bytes_per_slot, hipStream_t s) {
+    int st = pb_reserve_val(g->pb, bytes_per_slot, s);
+    if (st == GT_OK && g->pb_wide) st = pb_reserve_val(g->pb_wide, 4, s);
+    return st;
+}
+uint32_t gt_pb_val_allocs(const gt_graph *g) { return (g->pb ? g->pb->val_allocs : 0) + (g->pb_wide ? g->pb_wide->val_allocs : 0); }
 
-const uint8_t *gt_pb_bin_single(const gt_graph *g) { return g->pb ? g->pb->bin_single : nullptr; }
-const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n) { *n = g->pb ? g->pb->nsplit : 0; return g->pb ? g->pb->split_bins : nullptr; }
+// `wide`: the build the SpMV in question ran on (gt_pb_uses_wide): the two builds cut their row bins into workgroups independently
+static inline const gt_pb *pb_of(const gt_graph *g, bool wide) { return wide && g->pb_wide ? g->pb_wide : g->pb; }
+// the SpMVs with 4-byte messages: PageRank's f32 ones, and the min semirings (u32) when the graph was built with GRAPHTAP_PB_WIDE=1
+bool gt_pb_uses_wide(const gt_graph *g, int semiring, bool f32_messages) {
+    return g->pb_wide != nullptr && ((semiring == GT_PLUS_F64 && f32_messages) || semiring == GT_MIN_U32 || semiring == GT_MINPLUS_U32);
+}
+const uint8_t *gt_pb_bin_single(const gt_graph *g, bool wide) { const gt_pb *pb = pb_of(g, wide); return pb ? pb->bin_single : nullptr; }
+const uint32_t *gt_pb_split_bins(const gt_graph *g, uint32_t *n, bool wide) { const gt_pb *pb = pb_of(g, wide); *n = pb ? pb->nsplit : 0; return pb ? pb->split_bins : nullptr; }
 // running totals of the hybrid passes of this graph: [0] passes, [1] entries handed to the column-driven kernels, [2] entries of the
 // windows left out of the streaming pass, [3] such windows (diagnostic; tools/bench_apps.py)
 extern "C" int gt_graph_hybrid_stats(const gt_graph *g, uint64_t *out4, int reset) {
@@ -1763,16 +1849,15 @@ const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n
     *n = g->pb->split_part[k + 1] - g->pb->split_part[k];
     return g->pb->split_bins + g->pb->split_part[k];
 }
-uint32_t gt_pb_rows_single(const gt_graph *g) { return g->pb ? g->pb->rows_single : 0; }
+uint32_t gt_pb_rows_single(const gt_graph *g, bool wide) { const gt_pb *pb = pb_of(g, wide); return pb ? pb->rows_single : 0; }
 uint64_t gt_pb_source_entries(const gt_graph *g) { return g->pb ? g->pb->nnz_source : 0; }
 
 // A min program's initialize() takes the value stream over: 4-byte slots, every one infinity(), owner and epoch recorded -- what
 // the first streaming pass of its execute() would otherwise do first (a fill of 1.6 GB on R-MAT-26: 0.3 ms inside Execute time)
-int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hipStream_t s) {
-    gt_pb *pb = g->pb;
+static int pb_claim_val_min(const gt_graph *g, gt_pb *pb, const void *owner, uint64_t epoch, hipStream_t s) {
     if (!pb || pb->nnz == 0 || !pb->VAL) return GT_OK;
     if (pb->val_bytes != 4 || pb->val_kind != 3) { pb->val_bytes = 4; pb->val_kind = 3; }
-    if (!pb->win_mode && pb->nwin && !gt_has_exchange(g)) {   // the buffers of the hybrid pass (pb_run): here, not inside the iteration loop
+    if (!pb->wide && !pb->win_mode && pb->nwin && !gt_has_exchange(g)) {   // the buffers of the hybrid pass (pb_run): here, not inside the iteration loop
         // candidates: the windows that hold at least 1/256 of all entries each (GRAPHTAP_HYBRID_MIN_DIV; tests: a huge divisor = every window)
         const char *ed = getenv("GRAPHTAP_HYBRID_MIN_DIV");
         const uint64_t div = ed ? (uint64_t)std::max(1ll, atoll(ed)) : 256;
@@ -1795,10 +1880,17 @@ int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hi
     return GT_OK;
 }
 
+int gt_pb_claim_val_min(const gt_graph *g, const void *owner, uint64_t epoch, hipStream_t s) {
+    int st = pb_claim_val_min(g, g->pb, owner, epoch, s);
+    if (st == GT_OK && g->pb_wide) st = pb_claim_val_min(g, g->pb_wide, owner, epoch, s);
+    return st;
+}
+
 int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStream_t s, bool f32_messages, bool x_is_f32,
                const void *owner, uint64_t epoch, uint32_t slice_lo, uint32_t slice_hi, unsigned phases, const gt_pr_epilogue *epi, bool skip_source,
                uint32_t part_lo, uint32_t part_hi) {
-    gt_pb *pb = g->pb;
+    const bool wide = gt_pb_uses_wide(g, semiring, f32_messages);   // 4-byte PageRank messages on a graph that has the wide build
+    gt_pb *pb = wide ? g->pb_wide : g->pb;
     GT_REQUIRE(pb, GT_ERR_STATE, "propagation-blocking structures were not built for this graph");
     if (pb->nnz == 0) return GT_OK;
     const uint32_t K = g->info.x_slices;
@@ -1809,19 +1901,26 @@ int gt_pb_spmv(const gt_graph *g, int semiring, const void *x, void *y, hipStrea
     const int kind = (semiring == GT_PLUS_F64) ? (f32_messages ? 1 : 2) : 3;
     if ((phases & GT_PB_PREPARE) && (pb->val_bytes != need || pb->val_kind != kind)) {
         // programs reserve the stream in initialize() (gt_pb_reserve_val): this allocates only for a bare gt_spmv
-        { int st = gt_pb_reserve_val(g, need, s); if (st != GT_OK) return st; }
+        { int st = pb_reserve_val(pb, need, s); if (st != GT_OK) return st; }
         pb->val_bytes = need; pb->val_kind = kind; pb->val_min = -1; pb->val_owner = nullptr;   // re-fill for the new element type
     }
     switch (semiring) {
         case GT_PLUS_F64:
             GT_REQUIRE(!x_is_f32 || f32_messages, GT_ERR_STATE, "f32 message vector with an f64-message SpMV variant");
+            if (f32_messages && x_is_f32 && wide) return pb_run<double, float, float, false, false, uint32_t, true>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
+            if (f32_messages && wide) return pb_run<double, float, double, false, false, uint32_t, true>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
             if (f32_messages && x_is_f32) return pb_run<double, float, float, false, false>(g, pb, (const float *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
             if (f32_messages) return pb_run<double, float, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
             return pb_run<double, double, double, false, false>(g, pb, (const double *)x, (double *)y, s, nullptr, 0, slice_lo, slice_hi, phases, epi, skip_source, part_lo, part_hi);
         case GT_PLUS_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, false>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, nullptr, 0, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
-        case GT_MIN_U32: return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+        case GT_MIN_U32:
+            if (wide) return pb_run<uint32_t, uint32_t, uint32_t, false, true, uint32_t, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+            return pb_run<uint32_t, uint32_t, uint32_t, false, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
         case GT_MINPLUS_U32:
             GT_REQUIRE(pb->WT, GT_ERR_INVALID, "min-plus SpMV needs a weighted graph");
+            if (wide && pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+            if (wide && pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
+            if (wide) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t, true>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
             if (pb->wt_bytes == 1) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint8_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
             if (pb->wt_bytes == 2) return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint16_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);
             return pb_run<uint32_t, uint32_t, uint32_t, true, true, uint32_t>(g, pb, (const uint32_t *)x, (uint32_t *)y, s, owner, epoch, slice_lo, slice_hi, phases, nullptr, false, part_lo, part_hi);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects what profiles/r03/ holds, on a GPU box, in two parts of < 20 minutes (outputs under gpurun_out/final/; copy into profiles/ afterwards):
+# Collects what profiles/r04/ (round 3: profiles/r03/) holds, on a GPU box, in two parts of < 20 minutes (outputs under gpurun_out/final/; copy into profiles/ afterwards):
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh A'
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh B'
 set -e
@@ -13,7 +13,7 @@ if [ "$1" == "A" ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq/x -o p -- python3 bench.py --no-cpu-baseline --no-f64 --steps 20 --warmup 0 > /dev/null 2>&1
-  python3 profiles/collect_pmc.py $O/pmc_fetch $O/pmc_write scale26_gpus1 $O/pmc_traffic.json > /dev/null
+  GRAPHTAP_COMMIT=${GRAPHTAP_COMMIT:-unknown} python3 profiles/collect_pmc.py $O/pmc_fetch $O/pmc_write scale26_gpus1 $O/pmc_traffic.json > /dev/null
   GRAPHTAP_PB_STATS=1 python bench.py --no-cpu-baseline --no-f64 --steps 2 --warmup 1 2>&1 >/dev/null | grep -E "^\[pb\]|^\[build\]" > $O/pb_build_stats_rmat26.txt || true
   GRAPHTAP_PB_PHASE_TIMING=1 python bench.py --no-cpu-baseline > $O/bench_with_phase_times.json 2>/dev/null
   python bench.py --no-cpu-baseline --scale 22 > $O/bench_scale22.json 2>/dev/null
