@@ -1275,7 +1275,10 @@ int gt_pb_build(gt_graph *g) {
     // gt_spmv) keep the narrow build (an f64 window of that width would be 256 KiB). GRAPHTAP_PB_WIDE=0 / 1: never / for every graph
     // without an exchange layout.
     const char *ew = gt_cfg(g, "GRAPHTAP_PB_WIDE");
-    const bool want = ew ? atoi(ew) != 0 : g->spmv_variant == GT_SPMV_PB_F32MSG;
+    // ... by default only from ~0.8 G stored entries: measured by scale (profiles/r04/ab_wide_windows_by_scale.txt, PageRank f32 messages,
+    // narrow -> wide): R-MAT-22 458 -> 423 GTEPS, 23: 536 -> 547, 24: 662 -> 633, 25: 716 -> 698, 26: 686 -> 710 -- phase 1 pays its
+    // +18 % everywhere, phase 2's -20 % outweighs it only on the largest graph.
+    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (3ull << 28));
     if (want && !g->pb_wide && !gt_has_exchange(g) && g->info.nnz_local) { gt_pb *pb = nullptr; int st = pb_build_impl(g, true, &pb); if (st != GT_OK) return st; g->pb_wide = pb; }
     return GT_OK;
 }

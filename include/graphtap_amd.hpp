@@ -150,7 +150,9 @@ struct Env {
 
 class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hpp:31-71
   public:
-    explicit Graph(bool weighted = false) : weighted_(weighted) {}
+    explicit Graph(bool weighted = false) : weighted_(weighted) { gt_graph_options_init(&opt_); }
+    // handle-level configuration instead of the GRAPHTAP_* environment variables (gt_graph_options, ABI 3): set before load()
+    gt_graph_options &options() { has_opt_ = true; return opt_; }
     ~Graph() {}  // like the reference: free() is explicit (graph.hpp:73-81)
 
     void load(const std::string &filepath, uint32_t nrows, uint32_t ncols, bool directed = true, bool transpose = false,
@@ -183,7 +185,7 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
             GT_MASTER_PRINTF("%s: Read %llu edges\n", filepath.c_str(), (unsigned long long)m);
             free();
             gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
-            check(gt_graph_build_distributed(&h_, Env::dist(), share.data(), hi - lo, 0, weighted_, nrows, &f));
+            check(gt_graph_build_opt(&h_, Env::dist(), share.data(), hi - lo, 0, weighted_, nrows, &f, Env::rank(), Env::nranks(), has_opt_ ? &opt_ : nullptr));
             after_build(compression_type);
         } else {
             buf.resize((size_t)bytes);
@@ -237,7 +239,7 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
         free();
         gt_graph_flags f{directed, transpose, self_loops, acyclic, parallel_edges};
         // (an in-memory list: every rank passes all of it and keeps its tile-row; files go through the distributed build above)
-        check(gt_graph_build(&h_, edges, m, on_device, weighted_, num_vertices, &f, Env::rank(), Env::nranks()));
+        check(gt_graph_build_opt(&h_, nullptr, edges, m, on_device, weighted_, num_vertices, &f, Env::rank(), Env::nranks(), has_opt_ ? &opt_ : nullptr));
         after_build(compression_type);
     }
     void after_build(Compression_type compression_type) {
@@ -256,6 +258,7 @@ class Graph {  // Graph<Weight, Integer_Type, Fractional_Type>, src/mat/graph.hp
 
   private:
     bool weighted_;
+    gt_graph_options opt_{}; bool has_opt_ = false;
     gt_graph *h_ = nullptr;
 };
 
@@ -334,6 +337,8 @@ class Vertex_Program {  // src/vp/vertex_program.hpp:23-62
     void free() {
         if (h_) { check(gt_program_free(h_)); h_ = nullptr; }
     }
+    // handle-level configuration of this program (gt_program_options, ABI 3): e.g. { gt_program_options o; gt_program_options_init(&o); o.timeout_s = 30; V.set_options(o); }
+    void set_options(const gt_program_options &o) { check(gt_program_set_options(handle(), &o)); }
     gt_program *handle() {
         if (!h_) {
             gt_program_params p{kind_, order_, G_.compression == _TCSC_CF_ ? GT_TCSC_CF : GT_TCSC, root, alpha, tol};

@@ -1138,6 +1138,55 @@ def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatc
     G.free(); ref["graph"].close(); want["graph"].close()
 
 
+@pytest.mark.parametrize("hub_deg", [None, "2", "1000000"])
+def test_wide_build_gives_the_same_results(gt, O, hub_deg, known_answers, monkeypatch):
+    """The WIDE propagation-blocking build (pb.hip, gt_pb::wide; round 4): windows of 32 766 / 32 768 slots -- pairs of the layout's
+    windows -- 15 column bits, the run heads as a mask in the group record. By default only graphs of ~0.8 G entries and more get it
+    (the full-size headline tests run on it); here GRAPHTAP_PB_WIDE=1 builds it for small and mid-size graphs: PageRank with f32
+    messages against the reference's vectors and the oracle (fixed count, hand-stepped without the fused applicator, and converge
+    mode -- which runs f64 messages on the NARROW build of the same graph), and -- the same switch sends the min programs
+    through it too -- BFS / SSSP / CC bit for bit incl. iteration counts. Hub thresholds 2 / none: many / no dense windows, an odd
+    number of them included; R-MAT-16 and 18 have separate chunks for source rows whose short runs put run heads in every lane
+    (a first version sign-extended the low word of the head mask: a head in lane 31 became heads in lanes 32-63)."""
+    from graphtap_amd.rmat import rmat_edges
+    L = gt._lib.lib()
+    monkeypatch.setenv("GRAPHTAP_PB_WIDE", "1"); monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")
+    if hub_deg: monkeypatch.setenv("GRAPHTAP_PB_HUB_DEG", hub_deg)
+    for name in CASES:
+        c = load_case(name); nv = c["num_vertices"]; n = nv + 1; k = known_answers[name]
+        r = run_pr(gt, c["edges"], nv, 20)
+        assert (np.abs(r["rank"][:n] - c["np1_pr20_c"]) / c["np1_pr20_c"]).max() < PR_RTOL and (r["degree"][:n] == c["np1_pr20_a"]).all()
+        r = run_pr(gt, c["edges"], nv, 0)
+        assert r["iterations"] == k["np1_prconv_cf"]["iterations"] and (np.abs(r["rank"][:n] - c["np1_prconv_cf_c"]) / c["np1_prconv_cf_c"]).max() < PR_RTOL
+        r = run_min(gt, "bfs", c["edges"], nv, c["root"])
+        assert (r["parent"][:n] == c["np1_bfs_a"]).all() and r["iterations"] == k["np1_bfs"]["iterations"]
+        r = run_min(gt, "sssp", c["wedges"], nv, c["root"])
+        assert (r["distance"][:n] == c["np1_sssp_a"]).all() and r["iterations"] == k["np1_sssp"]["iterations"]
+        r = run_min(gt, "cc", c["edges"], nv)
+        assert (r["label"][:n] == c["np1_cc_a"]).all() and r["iterations"] == k["np1_cc"]["iterations"]
+    for scale, seed in ((16, 5), (18, 5)):
+        nv = 1 << scale; w = rmat_edges(scale, 16, seed, weighted=True); e = np.ascontiguousarray(w[:, :2])
+        ref = O.run_app("pr", e, nv, iters=10)
+        G = gt.Graph(); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+        V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+        P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(10)
+        assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+        P.initialize(V); h = P._handle()
+        for it in range(10):   # stepped by hand, the applicator fused in two iterations of three
+            gt._lib.check(L.gt_program_scatter_gather(h))
+            if it % 3 != 1: gt._lib.check(L.gt_program_fuse_apply(h, 10, 0))
+            gt._lib.check(L.gt_program_combine(h)); gt._lib.check(L.gt_program_apply(h, 10, None))
+        assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+        P.free(); V.free(); G.free(); ref["graph"].close()
+        if scale == 16:
+            want = O.run_app("sssp", w, nv, root=0); got = run_min(gt, "sssp", w, nv, 0)
+            assert (got["distance"] == want["distance"]).all() and got["iterations"] == want["iterations"]
+            want["graph"].close()
+            want = O.run_app("cc", e, nv); got = run_min(gt, "cc", e, nv)
+            assert (got["label"] == want["label"]).all() and got["iterations"] == want["iterations"]
+            want["graph"].close()
+
+
 def test_multirank_tile_rows_are_balanced(gt):
     """Contiguous id ranges of R-MAT are badly skewed (tile-row 0 of 8 would hold ~44 % of the entries); the hashed
     internal id space must give every rank a similar share of entries, rows and columns."""
