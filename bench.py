@@ -215,6 +215,7 @@ def main():
         G.load_device(d.value, m, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=rank, nranks=world)  # apps/pr.cpp:26-36
         build_kind = "replicated: every rank sees all records and keeps its tile-row" if dist_on else "single rank"
     _lib.check(L.gt_free(d))
+    wide_build = bool(L.gt_graph_has_wide_build(G._h))   # windows of 32 766 slots for the 4-byte-message SpMVs
     V = gt.Deg_Program(G, True, False, False, gt._COL_)   # apps/pr.cpp:37-42
     V.execute(1)
     VR = gt.PR_Program(G, True, False, False, gt._ROW_)   # apps/pr.cpp:46-50
@@ -350,7 +351,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.spmv != "pb_f32msg" else "f64 accumulate / f32 messages", "data": "synthetic",
         "config": {"workload": "PageRank R-MAT scale %d edge-factor 16 seed %d, flags of apps/pr.cpp (TCSC_CF), 1 step = 1 iteration" % (scale, args.seed),
                    "num_vertices": nv, "edge_records": m, "stored_entries": nnz, "nnzrows": int(G.nnzrows_global), "nnzcols": int(i.nnzcols_global),
-                   "spmv": args.spmv, "applicator": "rank / changed flags stored by the last two iterations only (dead stores elided; GRAPHTAP_PR_LEAN_STATE=0: every iteration)" if lean else "full state every iteration",
+                   "spmv": args.spmv, "pb_build": ("wide: 32 766-slot windows for the f32-message SpMVs, the narrow build beside it for f64 messages" if wide_build and args.spmv == "pb_f32msg" else "narrow: 16 383-slot windows"), "applicator": "rank / changed flags stored by the last two iterations only (dead stores elided; GRAPHTAP_PR_LEAN_STATE=0: every iteration)" if lean else "full state every iteration",
                    "partition": "tile-rows x%d (1-D), needed-columns all-to-all of x per step" % world if dist_on else "single tile",
                    "driver": ("C++ gt_dist_execute over RCCL" if args.driver == "native" and args.backend == "nccl" else "python dist.run over torch.distributed/" + args.backend) if dist_on else "C++ gt_program_execute",
                    "ingress_s": round(t_ingress, 3), "build": build_kind, "iterations_total": iterations_total, "value_checksum": checksum[0], "reachable": checksum[1]},

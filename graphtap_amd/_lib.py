@@ -107,6 +107,7 @@ SIGNATURES = {
     "gt_graph_build_opt": (C.c_int, [C.POINTER(_vp), _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.POINTER(GraphFlags), C.c_int, C.c_int, C.POINTER(GraphOptions)]),
     "gt_program_set_options": (C.c_int, [_vp, C.POINTER(ProgramOptions)]),
     "gt_graph_info_get": (C.c_int, [_vp, C.POINTER(GraphInfo)]),
+    "gt_graph_has_wide_build": (C.c_int, [_vp]),
     "gt_graph_select_spmv": (C.c_int, [_vp, C.c_int]),
     "gt_graph_vertex_ids": (C.c_int, [_vp, _vp, C.c_uint64]),
     "gt_graph_tile": (C.c_int, [_vp, C.POINTER(TileArrays)]),

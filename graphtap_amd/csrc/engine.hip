@@ -532,6 +532,7 @@ int gt_graph_select_spmv(gt_graph *g, int variant) {
     return GT_OK;
 }
 
+int gt_graph_has_wide_build(const gt_graph *g) { return g && g->pb_wide ? 1 : 0; }
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info) {
     GT_REQUIRE(g && info, GT_ERR_INVALID, "null argument");
     *info = g->info;

@@ -264,6 +264,9 @@ void gt_program_options_init(gt_program_options *o);
 int gt_graph_build_opt(gt_graph **out, gt_dist *dist, const void *edges, uint64_t m, int edges_on_device, int weighted,
                        uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, const gt_graph_options *opt);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
+/* 1 when the graph also carries the WIDE propagation-blocking build (windows of twice the width, used by SpMVs with 4-byte PageRank
+ * messages; built for GT_SPMV_PB_F32MSG graphs of ~0.8 G entries and more on one rank, or on request: GRAPHTAP_PB_WIDE), else 0 */
+int gt_graph_has_wide_build(const gt_graph *g);
 /* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
  * GT_SPMV_PB; GT_SPMV_PB_F32MSG / GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=pb_f32msg / edge at build time). */
 int gt_graph_select_spmv(gt_graph *g, int variant);
