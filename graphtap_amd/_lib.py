@@ -66,7 +66,7 @@ class GraphOptions(C.Structure):
     """gt_graph_options: per-handle configuration of a graph build (unset fields fall back to the environment)."""
     _fields_ = [("size", C.c_uint32), ("spmv_variant", C.c_int32), ("force_exchange", C.c_int32), ("x_slices", C.c_uint32),
                 ("hubs_first", C.c_int32), ("hub_min_degree", C.c_uint32), ("exchange_hub_min", C.c_uint32), ("chunk_log2", C.c_uint32),
-                ("reserved", C.c_uint32 * 8)]
+                ("wide_windows", C.c_int32), ("reserved", C.c_uint32 * 7)]
 
     def __init__(self, **kw):
         super().__init__()

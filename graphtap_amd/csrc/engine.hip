@@ -417,7 +417,7 @@ int gt_graph_build_distributed(gt_graph **out, gt_dist *dist, const void *edges_
 void gt_graph_options_init(gt_graph_options *o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
-    o->size = (uint32_t)sizeof(*o); o->spmv_variant = -1; o->force_exchange = -1; o->hubs_first = -1;
+    o->size = (uint32_t)sizeof(*o); o->spmv_variant = -1; o->force_exchange = -1; o->hubs_first = -1; o->wide_windows = -1;
 }
 void gt_program_options_init(gt_program_options *o) {
     if (!o) return;
@@ -453,6 +453,7 @@ static int graph_build_impl(gt_graph **out, const void *edges, uint64_t m, int e
         if (o.hub_min_degree) g->cfg.set("GRAPHTAP_PB_HUB_DEG", std::to_string(o.hub_min_degree));
         if (o.exchange_hub_min) g->cfg.set("GRAPHTAP_EXCHANGE_HUB_MIN", std::to_string(o.exchange_hub_min));
         if (o.chunk_log2) g->cfg.set("GRAPHTAP_PB_CH", std::to_string(o.chunk_log2));
+        if (o.wide_windows >= 0) g->cfg.set("GRAPHTAP_PB_WIDE", o.wide_windows ? "1" : "0");
     }
     g->flags = *flags;
     g->info.num_vertices = num_vertices;

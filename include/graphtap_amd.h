@@ -239,7 +239,9 @@ typedef struct gt_graph_options {
     uint32_t hub_min_degree;   /* entries from which a column is a hub; 0 unset: GRAPHTAP_PB_HUB_DEG, default 8 / 12 / 24 */
     uint32_t exchange_hub_min; /* the same inside a block of the exchange layout; 0 unset: GRAPHTAP_EXCHANGE_HUB_MIN, default 8 */
     uint32_t chunk_log2;       /* log2 entries per phase-1 chunk; 0 unset: GRAPHTAP_PB_CH, default by size (<= 19) */
-    uint32_t reserved[8];
+    int32_t wide_windows;      /* 1 always / 0 never: the WIDE propagation-blocking build beside the narrow one (gt_graph_has_wide_build);
+                                  -1 unset: GRAPHTAP_PB_WIDE, default for GT_SPMV_PB_F32MSG graphs of ~0.8 G entries and more on one rank */
+    uint32_t reserved[7];
 } gt_graph_options;
 typedef struct gt_program_options {
     uint32_t size;

@@ -52,7 +52,7 @@ def test_option_structs_start_unset():
     """gt_graph_options_init / gt_program_options_init (no GPU needed): every field at its "unset" value, size filled in."""
     from graphtap_amd import _lib
     g, p = _lib.GraphOptions(), _lib.ProgramOptions()
-    assert g.size == C.sizeof(_lib.GraphOptions) and (g.spmv_variant, g.force_exchange, g.hubs_first) == (-1, -1, -1)
+    assert g.size == C.sizeof(_lib.GraphOptions) and (g.spmv_variant, g.force_exchange, g.hubs_first, g.wide_windows) == (-1, -1, -1, -1)
     assert (g.x_slices, g.hub_min_degree, g.exchange_hub_min, g.chunk_log2) == (0, 0, 0, 0)
     assert p.size == C.sizeof(_lib.ProgramOptions) and p.timeout_s == 0.0
     assert all(getattr(p, f) == -1 for f in ("frontier_lists", "spmspv", "tail_kernel", "bfs_bottom_up", "cc_first", "fuse_apply", "lean_state", "hybrid"))

@@ -1100,16 +1100,18 @@ def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatc
     ref = O.run_app("pr", e, nv, iters=20)
     def width(P):   # bytes of a message of this program: 4 under GT_SPMV_PB_F32MSG (fixed-count runs), else 8
         wd = C.c_uint32(); gt._lib.check(gt._lib.lib().gt_program_x(P._handle(), None, None, C.byref(wd))); return wd.value
-    widths = []
+    widths, wide = [], []
     for opts in (gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, hub_min_degree=64, chunk_log2=14),
+                 gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, wide_windows=1),
                  gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_EDGE), gt.GraphOptions(hubs_first=0), None):
         G = gt.Graph(options=opts); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
         V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
         P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(20)
         assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
-        widths.append(width(P))
+        widths.append(width(P)); wide.append(gt._lib.lib().gt_graph_has_wide_build(G._h))
         P.free(); V.free(); G.free()
-    assert widths == [4, 8, 8, 8], widths          # the variants really differed inside one process
+    assert widths == [4, 4, 8, 8, 8], widths       # the variants really differed inside one process
+    assert wide == [0, 1, 0, 0, 0], wide           # ... and so did the builds: the wide windows for the one graph that asked for them
     monkeypatch.setenv("GRAPHTAP_SPMV", "pb_f32msg")    # ... and an option wins over the environment
     G = gt.Graph(options=gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB)); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
     V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
