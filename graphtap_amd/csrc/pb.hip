@@ -73,6 +73,7 @@ static uint32_t ch_default(const gt_graph *g, uint32_t nnz, uint32_t nwin) {
 constexpr uint32_t EPW = 1u << 19;     // value-stream slots per phase-2 workgroup: a bin below it keeps ONE workgroup, whose flush
                                        // can then apply PageRank's rows directly (2^18 and 2^19 stream equally fast, 2^20 is 2-10 % slower)
 constexpr int P1_THREADS = 1024;
+constexpr uint32_t P1_QUEUES = 64;   // counters of the persistent phase 1: launches that may be in flight at once
 constexpr int P2_THREADS = 1024;
 #ifndef GT_P2_U
 #define GT_P2_U 2
@@ -615,6 +616,12 @@ __global__ void __launch_bounds__(256) k_hybrid_long(const uint32_t *__restrict_
     }
 }
 
+#ifdef GT_EXP_TRACE   // timing experiment: per-workgroup start / end (100-MHz wall clock), what it worked on and where it ran (tools/p1_trace.py)
+__device__ unsigned long long gt_trace_p1[4 * 16384], gt_trace_p2[4 * 16384];
+__device__ __forceinline__ unsigned long long gt_trace_where() {
+    return ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+}
+#endif
 // ------------------------------------------------------------------ phase 1
 // T  = type of y and of the LDS accumulators (double or uint32_t)
 // TV = type of the value stream VAL and of the LDS message window: T, or float for the
@@ -805,7 +812,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
                                                            const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end,
-                                                           const uint8_t *__restrict__ win_mode) {
+                                                           const uint8_t *__restrict__ win_mode, uint32_t *__restrict__ queue, uint32_t nlaunch) {
     static_assert(W + 1 == WS, "dense and sparse chunks share one LDS window");
     // the WIDE build (gt_pb::wide): windows of 2 W / 2 WS slots, 15 column bits, run heads as a mask in the group record
     constexpr uint32_t WIN = WIDE ? 2 * WS : WS, WD = WIDE ? 2 * W : W;
@@ -822,13 +829,26 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #ifndef GT_P1_STAGE_MIN
 #define GT_P1_STAGE_MIN 0
 #endif
+#ifndef GT_P1_FIRST_LAST
+#define GT_P1_FIRST_LAST 1   // (-1.8 % of phase 1, ten rounds of A/B on one box: profiles/r04/ab_first_last_and_persistent.txt)
+#endif
+#ifndef GT_P1_PERSIST_DEFAULT
+#define GT_P1_PERSIST_DEFAULT 1
+#endif
     constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
     __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 1];
-    const uint32_t c = launch_order[chunk0 + blockIdx.x];   // largest chunks first (see gt_pb_build)
+    auto chunk = [&](const uint32_t bi) {   // one chunk: position bi of the launch
+    const uint32_t c = launch_order[chunk0 + bi];   // largest chunks first (see gt_pb_build)
     const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)
     // ONE launch for both kinds of chunks (dense ones first, largest first; the light sparse ones fill the tail): two launches
     // cost a drain of the 64-KiB workgroups in between
     const bool sparse = col0 >= dense_end;
+#ifdef GT_EXP_TRACE
+    if (threadIdx.x == 0 && bi < 16384) {
+        gt_trace_p1[4 * bi] = wall_clock64(); gt_trace_p1[4 * bi + 2] = ((unsigned long long)c << 32) | (q1c - q0c);
+        gt_trace_p1[4 * bi + 3] = gt_trace_where();
+    }
+#endif
     if constexpr (IS_MIN) {
         // hybrid pass (pb_run): a window whose few active columns went to the column-driven SpMSpV -- or that has none -- is left out
         // here without even staging it; its value-stream slots keep older messages of the same program (y is a running min)
@@ -946,10 +966,24 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                 continue;
             }
             TV *__restrict__ st = stage[wave];
+#if GT_P1_FIRST_LAST
+            // The lane's FIRST output -- the one that also closes what the lanes below left open -- is written LAST, over whatever
+            // the predicated stores put into its slot (LDS stores of one wave land in order): one select chain and one combine
+            // instead of a combine, a compare and a select per output. Bit-identical (the same two operands are combined).
+            {
+                TV *__restrict__ sp = st + i0;
+                const TV first = comb(carry, e0 ? v0 : (e1 ? a1 : (e2 ? a2 : a3)));
+                if (e1) sp[n0] = a1;
+                if (e2) sp[n1] = a2;
+                if (e3) sp[n2] = a3;
+                if (__builtin_amdgcn_inverse_ballot_w64(E0 | E1 | E2 | E3)) sp[0] = first;   // (the wave-uniform mask the scan already holds)
+            }
+#else
             if (e0) st[i0] = comb(carry, v0);
             if (e1) st[i0 + n0] = n0 ? a1 : comb(carry, a1);
             if (e2) st[i0 + n1] = n1 ? a2 : comb(carry, a2);
             if (e3) st[i0 + n2] = n2 ? a3 : comb(carry, a3);
+#endif
             // out: output i of the group goes to k-slot i + (the constant of its run); 64 consecutive outputs per store. The
             // constants come off the group record with scalar reads: dword 0 for the run the group starts in, dword j for the run
             // of its j-th head (lane j of gw holds dword j), KSTART for heads beyond the sixth.
@@ -985,6 +1019,29 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #pragma unroll
         for (int u = 0; u < U; u++) { lc[u] = nlc[u]; gw[u] = ngw[u]; w[u] = nw[u]; }
     }
+#ifdef GT_EXP_TRACE
+    if (lane == 0 && bi < 16384) atomicMax(&gt_trace_p1[4 * bi + 1], (unsigned long long)wall_clock64());
+#endif
+    };
+    // PERSISTENT form (queue != nullptr): as many workgroups as the chip holds at once, each drawing the next position of the launch
+    // order from a counter -- no dispatch between a CU's chunks, and a free CU never waits behind a workgroup that the dispatcher
+    // has promised to another XCD. Every workgroup overshoots exactly once; the one that draws the very last number of the launch
+    // (nlaunch + gridDim.x - 1) puts the counter back to zero for the next launch that uses it.
+    if (queue) {
+        // (the kernel's LDS is spoken for to the last byte -- 2 x 80 KiB / 160 KiB per CU: the number drawn travels through the first
+        // word of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
+        volatile uint32_t *next_bi = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
+        for (;;) {
+            __syncthreads();   // every wave is done with the window and with its staging row
+            if (threadIdx.x == 0) { const uint32_t i = atomicAdd(queue, 1u); if (i == nlaunch + gridDim.x - 1) atomicExch(queue, 0u); *next_bi = i; }
+            __syncthreads();
+            const uint32_t bi = *next_bi;
+            if (bi >= nlaunch) break;
+            chunk(bi);
+        }
+        return;
+    }
+    chunk(blockIdx.x);
 }
 
 // ------------------------------------------------------------------ phase 2
@@ -1002,11 +1059,24 @@ template <class T, bool IS_MIN> __device__ __forceinline__ void lds_combine(T *a
 template <class T, class TV, bool IS_MIN, int FUSE>
 __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restrict__ work, const C4 *__restrict__ LROW4,
                                                           const V4<TV> *__restrict__ VAL4, uint32_t nrows, T *__restrict__ y,
-                                                          const uint32_t *__restrict__ active_prefix, gt_pr_epilogue epi) {
+                                                          const uint32_t *__restrict__ active_prefix, gt_pr_epilogue epi,
+                                                          uint32_t *__restrict__ queue, uint32_t nlaunch) {
     __shared__ T acc[R + 1];   // row R: the dummy row every pad output targets
-    const BinWork wk = work[blockIdx.x];
+    __shared__ unsigned wsum[P2_THREADS / 64];
+    __shared__ uint32_t next_bi;
+    auto item = [&](const uint32_t bi) {   // one entry of the work list: position bi of the launch
+    const BinWork wk = work[bi];
     if (active_prefix && active_prefix[wk.c_hi + 1] == active_prefix[wk.c_lo]) return;   // no active chunk feeds this slice
     const T neutral = IS_MIN ? (T)GT_INF : (T)0;
+#ifdef GT_EXP_TRACE
+    if (threadIdx.x == 0 && bi < 8192) {
+        gt_trace_p2[8 * bi] = wall_clock64(); gt_trace_p2[8 * bi + 3] = gt_trace_where();
+        gt_trace_p2[8 * bi + 4] = ((unsigned long long)wk.bin << 32) | (wk.k1 - wk.k0); gt_trace_p2[8 * bi + 5] = wk.single;
+    }
+#define GT_TRACE_P2_END() do { if ((threadIdx.x & 63) == 0 && bi < 8192) atomicMax(&gt_trace_p2[8 * bi + 2], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define GT_TRACE_P2_END() do { } while (0)
+#endif
     for (uint32_t i = threadIdx.x; i <= R; i += P2_THREADS) acc[i] = neutral;
     __syncthreads();
     // 4 consecutive entries per lane per load (16-byte VAL loads for f32/u32 streams, 2 x 16 B for f64;
@@ -1029,6 +1099,9 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
         for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
     }
     __syncthreads();
+#ifdef GT_EXP_TRACE
+    if (threadIdx.x == 0 && bi < 8192) gt_trace_p2[8 * bi + 1] = wall_clock64();   // the stream has been combined
+#endif
     const uint32_t row0 = wk.bin << RB;
     const uint32_t rn = (nrows - row0 < R) ? nrows - row0 : R;
 #ifdef GT_EXP_P2_NO_FLUSH   // timing experiment (wrong results): the workgroup ends when its stream has been combined
@@ -1077,7 +1150,6 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                 }
             }
             if (epi.d_active) {   // one atomic per workgroup
-                __shared__ unsigned wsum[P2_THREADS / 64];
                 for (int o = 32; o > 0; o >>= 1) act += __shfl_down(act, o);
                 if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = act;
                 __syncthreads();
@@ -1087,6 +1159,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                     if (t) atomicAdd(epi.d_active, (unsigned long long)t);
                 }
             }
+            GT_TRACE_P2_END();
             return;
         }
     }
@@ -1102,9 +1175,32 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
             else atomicAdd(&y[row0 + i], a);
         }
     }
+    GT_TRACE_P2_END();
+    };
+    // persistent form, as in phase 1 (k_pb_scatter): one workgroup per slot of the chip, the work list drawn from a counter
+    if (queue) {
+        for (;;) {
+            __syncthreads();   // every wave is done with the accumulators (and has read next_bi)
+            if (threadIdx.x == 0) { const uint32_t i = atomicAdd(queue, 1u); if (i == nlaunch + gridDim.x - 1) atomicExch(queue, 0u); next_bi = i; }
+            __syncthreads();
+            const uint32_t bi = next_bi;
+            if (bi >= nlaunch) break;
+            item(bi);
+        }
+        return;
+    }
+    item(blockIdx.x);
 }
 
 }  // namespace
+#ifdef GT_EXP_TRACE
+extern "C" int gt_exp_trace_dump(unsigned long long *p1, unsigned long long *p2) {   // 4 x 16384 words each (experiment builds only; not in the header)
+    GT_HIP(hipDeviceSynchronize());
+    GT_HIP(hipMemcpyFromSymbol(p1, HIP_SYMBOL(gt_trace_p1), sizeof(unsigned long long) * 4 * 16384));
+    GT_HIP(hipMemcpyFromSymbol(p2, HIP_SYMBOL(gt_trace_p2), sizeof(unsigned long long) * 4 * 16384));
+    return GT_OK;
+}
+#endif
 
 struct gt_pb {
     bool wide = false;   // the WIDE build: windows of 2 W / 2 WS slots (128 KiB of 4-byte messages in LDS, one phase-1 workgroup per CU): ~12 % fewer value-stream slots
@@ -1133,6 +1229,9 @@ struct gt_pb {
     uint32_t val_allocs = 0;   // allocations of VAL so far (gt_exec_stats.allocs_in_execute counts those made inside execute())
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice (and kind), largest chunk first
+    // persistent phase 1 (k_pb_scatter, `queue`): a ring of zeroed counters, one per launch in flight (slices of an exchange layout run
+    // side by side on streams of their own), and the CUs of the device
+    uint32_t *p1_queue = nullptr; uint32_t p1_seq = 0; int ncu = 0;
     uint8_t *bin_single = nullptr;      // [nbins] 1 = the bin has exactly one phase-2 workgroup
     uint32_t *split_bins = nullptr;     // [nsplit] the other bins (with entries): their rows go through y and the apply kernel
     uint32_t nsplit = 0;
@@ -1163,7 +1262,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->bin_single, pb->split_bins,
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->p1_queue, pb->bin_single, pb->split_bins,
                     pb->win_entries, pb->xdeg, pb->win_act, pb->win_mode, pb->hy_col, pb->hy_val, pb->hy_deg, pb->hy_long, pb->hy_cnt, pb->hy_stat, pb->hy_cand};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : pb->pt_ev) (void)hipEventDestroy(e);
@@ -1654,6 +1753,8 @@ static int pb_build_impl(gt_graph *g, bool wide, gt_pb **out) {
         }
         PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
         PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
+        PB_MALLOC(pb->p1_queue, P1_QUEUES * 4); PB_HIP(hipMemset(pb->p1_queue, 0, P1_QUEUES * 4));
+        { int dev = 0; hipDeviceProp_t prop; PB_HIP(hipGetDevice(&dev)); PB_HIP(hipGetDeviceProperties(&prop, dev)); pb->ncu = prop.multiProcessorCount; }
     }
     if (!wide) {   // window statistics for the min programs' hybrid pass (cheap: a few MB)
         pb->nwin = geom.nwin; pb->ndw_ = geom.ndw; pb->dense_end_ = geom.dense_end;
@@ -1745,10 +1846,20 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
     if (phases & GT_PB_PHASE1) {
         uint32_t *ca = filter ? pb->chunk_active : nullptr;
         auto scatter = [&](uint32_t c0, uint32_t c1) {
-            if (c1 > c0)
-                k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<c1 - c0, P1_THREADS, 0, s>>>(
-                    pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                    (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W, win_mode);
+            if (c1 <= c0) return;
+            // persistent: one workgroup per slot of the chip (the LDS window allows two per CU with 64 KiB, one with 128), each
+            // drawing chunks from a counter of the ring (GRAPHTAP_PB_PERSIST=0: one workgroup per chunk, dispatched in launch order)
+            // The plus semirings only: the min programs LOSE with it (CC R-MAT-24 2.1 -> 2.3 ms, SSSP 2.9 -> 3.1, CC R-MAT-26 8.1 -> 8.3;
+            // profiles/r04/ab_first_last_and_persistent.txt) -- their launches are mostly workgroups that leave at once (windows without
+            // an active column), which the dispatcher retires faster than a draw and two barriers do.
+            static const bool persist_on = !getenv("GRAPHTAP_PB_PERSIST") && GT_P1_PERSIST_DEFAULT && !IS_MIN;
+            static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 1) != 0;   // (A/B: bit 0 phase 1, bit 1 phase 2; 0 = neither)
+            const uint32_t slots = (uint32_t)pb->ncu * ((WIDE || sizeof(TV) == 8) ? 1u : 2u);
+            const bool persist = (persist_on || persist_forced) && pb->p1_queue && slots && c1 - c0 > slots;
+            uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
+            k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<persist ? slots : c1 - c0, P1_THREADS, 0, s>>>(
+                pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
+                (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W, win_mode, q, c1 - c0);
         };
         // one launch: [regular rows: dense, sparse][source rows: dense, sparse]; computation filtering (TCSC_CF) leaves the
         // source rows' chunks out of every iteration but the last
@@ -1765,15 +1876,23 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
         const BinWork *wk = pb->work + w0;
         const uint32_t nw = w1 - w0;
         if (nw) {
+            // persistent like phase 1: a slot per 128 KiB (f64) / 64 KiB (u32) of accumulators (GRAPHTAP_PB_PERSIST)
+            // -- built, measured, OFF (GRAPHTAP_PB_PERSIST=2 / 3 switches it on): the counter closes phase 2's dispatch gaps too (busy integral
+            // 91 -> 95 % of the launch) and its workgroups stream that much slower -- phase 2 runs at its mix's HBM rate either way
+            static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 2) != 0;
+            const uint32_t slots = (uint32_t)pb->ncu * (sizeof(T) == 8 ? 1u : 2u);
+            const bool persist = persist_forced && pb->p1_queue && slots && nw > slots;
+            uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
+            const uint32_t grid = persist ? slots : nw;
             if constexpr (std::is_same<T, double>::value) {
                 if (epi && epi->x_f32)
-                    k_pb_gather<T, TV, IS_MIN, 1><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+                    k_pb_gather<T, TV, IS_MIN, 1><<<grid, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi, q, nw);
                 else if (epi)
-                    k_pb_gather<T, TV, IS_MIN, 2><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi);
+                    k_pb_gather<T, TV, IS_MIN, 2><<<grid, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, *epi, q, nw);
                 else
-                    k_pb_gather<T, TV, IS_MIN, 0><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+                    k_pb_gather<T, TV, IS_MIN, 0><<<grid, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{}, q, nw);
             } else {
-                k_pb_gather<T, TV, IS_MIN, 0><<<nw, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{});
+                k_pb_gather<T, TV, IS_MIN, 0><<<grid, P2_THREADS, 0, s>>>(wk, (const C4 *)pb->LROW, (const V4<TV> *)pb->VAL, g->info.nnzrows, y, ap, gt_pr_epilogue{}, q, nw);
             }
         }
     }
