@@ -835,11 +835,14 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #ifndef GT_P1_PERSIST_DEFAULT
 #define GT_P1_PERSIST_DEFAULT 1
 #endif
+#ifndef GT_P1_ALL_ENDS
+#define GT_P1_ALL_ENDS 0
+#endif
     constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
-    __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 1];
-    auto chunk = [&](const uint32_t bi) {   // one chunk: position bi of the launch
-    const uint32_t c = launch_order[chunk0 + bi];   // largest chunks first (see gt_pb_build)
-    const uint32_t q0c = cv0[c] >> 2, q1c = cv1[c] >> 2, col0 = ccol0[c];   // the chunk's quad range (multiples of 64)
+    __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 8];
+    // one chunk: position bi of the launch = chunk c (largest chunks first, see gt_pb_build), its entry range [v0, v1) and first column
+    auto chunk = [&](const uint32_t bi, const uint32_t c, const uint32_t v0c, const uint32_t v1c, const uint32_t col0) {
+    const uint32_t q0c = v0c >> 2, q1c = v1c >> 2;   // the chunk's quad range (multiples of 64)
     // ONE launch for both kinds of chunks (dense ones first, largest first; the light sparse ones fill the tail): two launches
     // cost a drain of the 64-KiB workgroups in between
     const bool sparse = col0 >= dense_end;
@@ -938,7 +941,13 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #ifdef GT_EXP_P1_NO_SCAN   // timing experiment (wrong results): no segmented scan across the lanes
             const TV carry = e3 ? neutral : a3;
 #else
+#if GT_P1_ALL_ENDS   // a group whose 64 lanes all hold an end (the windows of short runs): a lane's carry is what the lane below leaves open -- one DPP move
+            TV carry;
+            if ((E0 | E1 | E2 | E3) == ~0ull) carry = dpp_get<0x138, 0xf, TV>(e3 ? neutral : a3, neutral);
+            else carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
+#else
             const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
+#endif
 #endif
 #if defined(GT_P1_SBURN) || defined(GT_P1_VBURN)   // experiment: extra dependent scalar / vector instructions per group (which issue port binds phase 1?)
             {
@@ -1028,20 +1037,36 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // has promised to another XCD. Every workgroup overshoots exactly once; the one that draws the very last number of the launch
     // (nlaunch + gridDim.x - 1) puts the counter back to zero for the next launch that uses it.
     if (queue) {
-        // (the kernel's LDS is spoken for to the last byte -- 2 x 80 KiB / 160 KiB per CU: the number drawn travels through the first
-        // word of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
-        volatile uint32_t *next_bi = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
+        // (the kernel's LDS is spoken for to the last byte -- 2 x 80 KiB / 160 KiB per CU: what was drawn travels through the first
+        // words of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
+        volatile uint32_t *mb = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
+        // Thread 0 draws a position and loads that chunk's description when the workgroup NEEDS it. (Drawing the next one at the START of
+        // the current chunk -- the atomic and the three dependent loads, ~3 us, in flight while the chunk runs -- was measured: phase 1
+        // 0.968 -> 1.015 ms, six rounds of A/B. A workgroup that has committed itself one chunk ahead is no longer the first free one
+        // when that chunk's turn comes: the list scheduling that persistence buys is lost again. GT_P1_DRAW_EARLY=1 builds that form.)
+        uint32_t nb = 0, nc = 0, nv0 = 0, nv1 = 0, ncol = 0;
+        auto draw = [&] {
+            nb = atomicAdd(queue, 1u);
+            if (nb == nlaunch + gridDim.x - 1) atomicExch(queue, 0u);
+            if (nb < nlaunch) { nc = launch_order[chunk0 + nb]; nv0 = cv0[nc]; nv1 = cv1[nc]; ncol = ccol0[nc]; }
+        };
+#ifndef GT_P1_DRAW_EARLY
+#define GT_P1_DRAW_EARLY 0
+#endif
+        if (GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
         for (;;) {
             __syncthreads();   // every wave is done with the window and with its staging row
-            if (threadIdx.x == 0) { const uint32_t i = atomicAdd(queue, 1u); if (i == nlaunch + gridDim.x - 1) atomicExch(queue, 0u); *next_bi = i; }
+            if (!GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
+            if (threadIdx.x == 0) { mb[0] = nb; mb[1] = nc; mb[2] = nv0; mb[3] = nv1; mb[4] = ncol; }
             __syncthreads();
-            const uint32_t bi = *next_bi;
+            const uint32_t bi = mb[0], c = mb[1], v0c = mb[2], v1c = mb[3], col0 = mb[4];
             if (bi >= nlaunch) break;
-            chunk(bi);
+            if (GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
+            chunk(bi, c, v0c, v1c, col0);
         }
         return;
     }
-    chunk(blockIdx.x);
+    { const uint32_t c = launch_order[chunk0 + blockIdx.x]; chunk(blockIdx.x, c, cv0[c], cv1[c], ccol0[c]); }
 }
 
 // ------------------------------------------------------------------ phase 2
@@ -1374,10 +1399,12 @@ int gt_pb_build(gt_graph *g) {
     // gt_spmv) keep the narrow build (an f64 window of that width would be 256 KiB). GRAPHTAP_PB_WIDE=0 / 1: never / for every graph
     // without an exchange layout.
     const char *ew = gt_cfg(g, "GRAPHTAP_PB_WIDE");
-    // ... by default only from ~0.8 G stored entries: measured by scale (profiles/r04/ab_wide_windows_by_scale.txt, PageRank f32 messages,
-    // narrow -> wide): R-MAT-22 458 -> 423 GTEPS, 23: 536 -> 547, 24: 662 -> 633, 25: 716 -> 698, 26: 686 -> 710 -- phase 1 pays its
-    // +18 % everywhere, phase 2's -20 % outweighs it only on the largest graph.
-    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (3ull << 28));
+    // ... by default from 2^25 stored entries. With workgroups dispatched one per chunk the wide build won on the largest graph only
+    // (profiles/r04/ab_wide_windows_by_scale.txt: R-MAT-22 458 -> 423 GTEPS, 24: 662 -> 633, 26: 686 -> 710 -- its single workgroup per CU
+    // paid every dispatch gap in full); with the persistent phase 1 (k_pb_scatter, `queue`) it wins from R-MAT-21 up (narrow -> wide,
+    // profiles/r04/ab_first_last_and_persistent.txt (7), (8)): R-MAT-20 162 -> 161 GTEPS, 21: 262 -> 275, 22: 404 -> 426, 23: 497 -> 557,
+    // 24: 584 -> 638, 26: +3 %.
+    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (1ull << 25));
     if (want && !g->pb_wide && !gt_has_exchange(g) && g->info.nnz_local) { gt_pb *pb = nullptr; int st = pb_build_impl(g, true, &pb); if (st != GT_OK) return st; g->pb_wide = pb; }
     return GT_OK;
 }
