@@ -835,9 +835,6 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #ifndef GT_P1_PERSIST_DEFAULT
 #define GT_P1_PERSIST_DEFAULT 1
 #endif
-#ifndef GT_P1_ALL_ENDS
-#define GT_P1_ALL_ENDS 0
-#endif
     constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
     __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 8];
     // one chunk: position bi of the launch = chunk c (largest chunks first, see gt_pb_build), its entry range [v0, v1) and first column
@@ -941,13 +938,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #ifdef GT_EXP_P1_NO_SCAN   // timing experiment (wrong results): no segmented scan across the lanes
             const TV carry = e3 ? neutral : a3;
 #else
-#if GT_P1_ALL_ENDS   // a group whose 64 lanes all hold an end (the windows of short runs): a lane's carry is what the lane below leaves open -- one DPP move
-            TV carry;
-            if ((E0 | E1 | E2 | E3) == ~0ull) carry = dpp_get<0x138, 0xf, TV>(e3 ? neutral : a3, neutral);
-            else carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
-#else
+            // (A wave-uniform shortcut for the groups whose 64 lanes ALL hold an end -- the windows of short runs; their carry is one DPP
+            // move -- was measured: phase 1 +1.3 %, six rounds: the branch costs every group more than the scan it saves a few.)
             const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
-#endif
 #endif
 #if defined(GT_P1_SBURN) || defined(GT_P1_VBURN)   // experiment: extra dependent scalar / vector instructions per group (which issue port binds phase 1?)
             {
