@@ -1875,7 +1875,10 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             static const bool persist_on = !getenv("GRAPHTAP_PB_PERSIST") && GT_P1_PERSIST_DEFAULT && !IS_MIN;
             static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 1) != 0;   // (A/B: bit 0 phase 1, bit 1 phase 2; 0 = neither)
             const uint32_t slots = (uint32_t)pb->ncu * ((WIDE || sizeof(TV) == 8) ? 1u : 2u);
-            const bool persist = (persist_on || persist_forced) && pb->p1_queue && slots && c1 - c0 > slots;
+            // Not on graphs with an exchange layout: the slices' launches run side by side with RCCL's kernels, which wait for a slot of
+            // their own as long as persistent workgroups hold every CU (R-MAT-26 through the exchange at world size 1: last slice in after
+            // 0.75 -> 1.59 ms, 1.96 -> 2.49 ms per step, bench_rmat26_forced_exchange_persistent_phase1_regression.json).
+            const bool persist = ((persist_on && !gt_has_exchange(g)) || persist_forced) && pb->p1_queue && slots && c1 - c0 > slots;
             uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
             k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<persist ? slots : c1 - c0, P1_THREADS, 0, s>>>(
                 pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
