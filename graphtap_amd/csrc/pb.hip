@@ -1029,37 +1029,47 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // order from a counter -- no dispatch between a CU's chunks, and a free CU never waits behind a workgroup that the dispatcher
     // has promised to another XCD. Every workgroup overshoots exactly once; the one that draws the very last number of the launch
     // (nlaunch + gridDim.x - 1) puts the counter back to zero for the next launch that uses it.
-    if (queue) {
-        // (the kernel's LDS is spoken for to the last byte -- 2 x 80 KiB / 160 KiB per CU: what was drawn travels through the first
-        // words of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
-        volatile uint32_t *mb = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
-        // Thread 0 draws a position and loads that chunk's description when the workgroup NEEDS it. (Drawing the next one at the START of
-        // the current chunk -- the atomic and the three dependent loads, ~3 us, in flight while the chunk runs -- was measured: phase 1
-        // 0.968 -> 1.015 ms, six rounds of A/B. A workgroup that has committed itself one chunk ahead is no longer the first free one
-        // when that chunk's turn comes: the list scheduling that persistence buys is lost again. GT_P1_DRAW_EARLY=1 builds that form.)
-        uint32_t nb = 0, nc = 0, nv0 = 0, nv1 = 0, ncol = 0;
-        auto draw = [&] {
-            nb = atomicAdd(queue, 1u);
-            if (nb == nlaunch + gridDim.x - 1) atomicExch(queue, 0u);
-            if (nb < nlaunch) { nc = launch_order[chunk0 + nb]; nv0 = cv0[nc]; nv1 = cv1[nc]; ncol = ccol0[nc]; }
-        };
-#ifndef GT_P1_DRAW_EARLY
-#define GT_P1_DRAW_EARLY 0
+    // ONE call site for both forms (the body inlined twice doubled the kernel's registers -- 39 -> 85 VGPRs in the 64-KiB-window
+    // kernels, which then fit one workgroup per CU instead of two: every program on the narrow build lost 5-12 %).
+    // (the kernel's LDS is spoken for to the last byte -- 2 x 80 KiB / 160 KiB per CU: what was drawn travels through the first
+    // words of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
+    volatile uint32_t *mb = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
+    // Thread 0 draws a position and loads that chunk's description when the workgroup NEEDS it. (Drawing the next one at the START of
+    // the current chunk -- the atomic and the three dependent loads, ~3 us, in flight while the chunk runs -- was measured: phase 1
+    // 0.968 -> 1.015 ms, six rounds of A/B. A workgroup that has committed itself one chunk ahead is no longer the first free one
+    // when that chunk's turn comes: the list scheduling that persistence buys is lost again.)
+    // Compiled in only where it is used: the kernels that fit ONE workgroup per CU (the wide window, f64 messages), where nothing else
+    // covers a dispatch gap. The two-per-CU kernels lose with it (f32 messages on the narrow build: R-MAT-22 460 -> 425 GTEPS, R-MAT-24
+    // 652 -> 640 -- a draw costs an atomic and dependent loads that a 10-us chunk does not amortise) and so do the min programs (see
+    // pb_run); GT_P1_PERSIST_ALL=1 compiles it into every instantiation (A/B with GRAPHTAP_PB_PERSIST=1).
+#ifndef GT_P1_PERSIST_ALL
+#define GT_P1_PERSIST_ALL 0
 #endif
-        if (GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
-        for (;;) {
+    constexpr bool CAN_PERSIST = GT_P1_PERSIST_ALL != 0 || (!IS_MIN && (WIDE || sizeof(TV) == 8));
+    if constexpr (!CAN_PERSIST) {
+        const uint32_t c = launch_order[chunk0 + blockIdx.x];
+        chunk(blockIdx.x, c, cv0[c], cv1[c], ccol0[c]);
+    } else
+    for (;;) {
+        uint32_t bi, c, v0c, v1c, col0;
+        if (queue) {
             __syncthreads();   // every wave is done with the window and with its staging row
-            if (!GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
-            if (threadIdx.x == 0) { mb[0] = nb; mb[1] = nc; mb[2] = nv0; mb[3] = nv1; mb[4] = ncol; }
+            if (threadIdx.x == 0) {
+                const uint32_t nb = atomicAdd(queue, 1u);
+                if (nb == nlaunch + gridDim.x - 1) atomicExch(queue, 0u);
+                mb[0] = nb;
+                if (nb < nlaunch) { const uint32_t nc = launch_order[chunk0 + nb]; mb[1] = nc; mb[2] = cv0[nc]; mb[3] = cv1[nc]; mb[4] = ccol0[nc]; }
+            }
             __syncthreads();
-            const uint32_t bi = mb[0], c = mb[1], v0c = mb[2], v1c = mb[3], col0 = mb[4];
+            bi = mb[0];
             if (bi >= nlaunch) break;
-            if (GT_P1_DRAW_EARLY && threadIdx.x == 0) draw();
-            chunk(bi, c, v0c, v1c, col0);
+            c = mb[1]; v0c = mb[2]; v1c = mb[3]; col0 = mb[4];
+        } else {
+            bi = blockIdx.x; c = launch_order[chunk0 + bi]; v0c = cv0[c]; v1c = cv1[c]; col0 = ccol0[c];
         }
-        return;
+        chunk(bi, c, v0c, v1c, col0);
+        if (!queue) break;
     }
-    { const uint32_t c = launch_order[chunk0 + blockIdx.x]; chunk(blockIdx.x, c, cv0[c], cv1[c], ccol0[c]); }
 }
 
 // ------------------------------------------------------------------ phase 2
@@ -1196,18 +1206,24 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
     GT_TRACE_P2_END();
     };
     // persistent form, as in phase 1 (k_pb_scatter): one workgroup per slot of the chip, the work list drawn from a counter
-    if (queue) {
-        for (;;) {
+    // (ONE call site for both forms: see k_pb_scatter)
+#ifndef GT_P2_PERSIST
+#define GT_P2_PERSIST 0   // (measured: no gain -- phase 2 runs at its mix's HBM rate with or without dispatch gaps; -DGT_P2_PERSIST=1 + GRAPHTAP_PB_PERSIST=2 for the A/B)
+#endif
+    if constexpr (GT_P2_PERSIST == 0) item(blockIdx.x);
+    else
+    for (;;) {
+        uint32_t bi = blockIdx.x;
+        if (queue) {
             __syncthreads();   // every wave is done with the accumulators (and has read next_bi)
             if (threadIdx.x == 0) { const uint32_t i = atomicAdd(queue, 1u); if (i == nlaunch + gridDim.x - 1) atomicExch(queue, 0u); next_bi = i; }
             __syncthreads();
-            const uint32_t bi = next_bi;
+            bi = next_bi;
             if (bi >= nlaunch) break;
-            item(bi);
         }
-        return;
+        item(bi);
+        if (!queue) break;
     }
-    item(blockIdx.x);
 }
 
 }  // namespace
@@ -1392,12 +1408,14 @@ int gt_pb_build(gt_graph *g) {
     // gt_spmv) keep the narrow build (an f64 window of that width would be 256 KiB). GRAPHTAP_PB_WIDE=0 / 1: never / for every graph
     // without an exchange layout.
     const char *ew = gt_cfg(g, "GRAPHTAP_PB_WIDE");
-    // ... by default from 2^25 stored entries. With workgroups dispatched one per chunk the wide build won on the largest graph only
-    // (profiles/r04/ab_wide_windows_by_scale.txt: R-MAT-22 458 -> 423 GTEPS, 24: 662 -> 633, 26: 686 -> 710 -- its single workgroup per CU
-    // paid every dispatch gap in full); with the persistent phase 1 (k_pb_scatter, `queue`) it wins from R-MAT-21 up (narrow -> wide,
-    // profiles/r04/ab_first_last_and_persistent.txt (7), (8)): R-MAT-20 162 -> 161 GTEPS, 21: 262 -> 275, 22: 404 -> 426, 23: 497 -> 557,
-    // 24: 584 -> 638, 26: +3 %.
-    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (1ull << 25));
+    // ... by default only from ~0.8 G stored entries: measured by scale (PageRank f32 messages, narrow -> wide). Workgroups dispatched
+    // per chunk (profiles/r04/ab_wide_windows_by_scale.txt): R-MAT-22 458 -> 423 GTEPS, 23: 536 -> 547, 24: 662 -> 633, 25: 716 -> 698,
+    // 26: 686 -> 710 -- phase 1 pays its +18 % everywhere, phase 2's -20 % outweighs it only on the largest graph. With the persistent
+    // phase 1 (profiles/r04/ab_recheck_after_register_fix.txt): R-MAT-20 174 -> 157, 21: 281 -> 273, 22: 422 -> 418, 24: 630 -> 633,
+    // 25: 715 -> 707 (ab_recheck_after_register_fix.txt, third block).
+    // (An A/B in between had the wide build win from R-MAT-21 up -- against a narrow kernel that a doubled register count had cut to
+    // one workgroup per CU; see k_pb_scatter, "ONE call site".)
+    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (3ull << 28));
     if (want && !g->pb_wide && !gt_has_exchange(g) && g->info.nnz_local) { gt_pb *pb = nullptr; int st = pb_build_impl(g, true, &pb); if (st != GT_OK) return st; g->pb_wide = pb; }
     return GT_OK;
 }
@@ -1869,16 +1887,18 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             if (c1 <= c0) return;
             // persistent: one workgroup per slot of the chip (the LDS window allows two per CU with 64 KiB, one with 128), each
             // drawing chunks from a counter of the ring (GRAPHTAP_PB_PERSIST=0: one workgroup per chunk, dispatched in launch order)
-            // The plus semirings only: the min programs LOSE with it (CC R-MAT-24 2.1 -> 2.3 ms, SSSP 2.9 -> 3.1, CC R-MAT-26 8.1 -> 8.3;
-            // profiles/r04/ab_first_last_and_persistent.txt) -- their launches are mostly workgroups that leave at once (windows without
-            // an active column), which the dispatcher retires faster than a draw and two barriers do.
+            // The plus semirings only: the min programs do not gain (BFS / CC R-MAT-26 +-1 %) or lose (SSSP R-MAT-24 3.09 -> 3.25 ms, R-MAT-26
+            // 10.25 -> 10.45; profiles/r04/ab_recheck_after_register_fix.txt) -- their launches are mostly workgroups that leave at once
+            // (windows without an active column), which the dispatcher retires faster than a draw and two barriers do.
             static const bool persist_on = !getenv("GRAPHTAP_PB_PERSIST") && GT_P1_PERSIST_DEFAULT && !IS_MIN;
             static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 1) != 0;   // (A/B: bit 0 phase 1, bit 1 phase 2; 0 = neither)
             const uint32_t slots = (uint32_t)pb->ncu * ((WIDE || sizeof(TV) == 8) ? 1u : 2u);
             // Not on graphs with an exchange layout: the slices' launches run side by side with RCCL's kernels, which wait for a slot of
-            // their own as long as persistent workgroups hold every CU (R-MAT-26 through the exchange at world size 1: last slice in after
-            // 0.75 -> 1.59 ms, 1.96 -> 2.49 ms per step, bench_rmat26_forced_exchange_persistent_phase1_regression.json).
-            const bool persist = ((persist_on && !gt_has_exchange(g)) || persist_forced) && pb->p1_queue && slots && c1 - c0 > slots;
+            // their own as long as persistent workgroups hold every CU (R-MAT-26 through the exchange at world size 1: 1.86 -> 1.97 ms
+            // per SpMV, ab_recheck_after_register_fix.txt; with the registers doubled on top: last slice in after 0.75 -> 1.59 ms,
+            // 1.96 -> 2.49 ms per step, bench_rmat26_forced_exchange_persistent_phase1_regression.json).
+            constexpr bool can_persist = GT_P1_PERSIST_ALL != 0 || (!IS_MIN && (WIDE || sizeof(TV) == 8));   // (what k_pb_scatter was compiled with)
+            const bool persist = can_persist && ((persist_on && !gt_has_exchange(g)) || persist_forced) && pb->p1_queue && slots && c1 - c0 > slots;
             uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
             k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<persist ? slots : c1 - c0, P1_THREADS, 0, s>>>(
                 pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
@@ -1904,7 +1924,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             // 91 -> 95 % of the launch) and its workgroups stream that much slower -- phase 2 runs at its mix's HBM rate either way
             static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 2) != 0;
             const uint32_t slots = (uint32_t)pb->ncu * (sizeof(T) == 8 ? 1u : 2u);
-            const bool persist = persist_forced && pb->p1_queue && slots && nw > slots;
+            const bool persist = GT_P2_PERSIST != 0 && persist_forced && pb->p1_queue && slots && nw > slots;
             uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
             const uint32_t grid = persist ? slots : nw;
             if constexpr (std::is_same<T, double>::value) {
