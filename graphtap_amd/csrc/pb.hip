@@ -1890,8 +1890,9 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             // The plus semirings only: the min programs do not gain (BFS / CC R-MAT-26 +-1 %) or lose (SSSP R-MAT-24 3.09 -> 3.25 ms, R-MAT-26
             // 10.25 -> 10.45; profiles/r04/ab_recheck_after_register_fix.txt) -- their launches are mostly workgroups that leave at once
             // (windows without an active column), which the dispatcher retires faster than a draw and two barriers do.
-            static const bool persist_on = !getenv("GRAPHTAP_PB_PERSIST") && GT_P1_PERSIST_DEFAULT && !IS_MIN;
-            static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 1) != 0;   // (A/B: bit 0 phase 1, bit 1 phase 2; 0 = neither)
+            const char *pe = getenv("GRAPHTAP_PB_PERSIST");   // (read per launch: the tests run both forms in one process)
+            const bool persist_on = !pe && GT_P1_PERSIST_DEFAULT && !IS_MIN;
+            const bool persist_forced = pe && (atoi(pe) & 1) != 0;   // (A/B: bit 0 phase 1, bit 1 phase 2; 0 = neither)
             const uint32_t slots = (uint32_t)pb->ncu * ((WIDE || sizeof(TV) == 8) ? 1u : 2u);
             // Not on graphs with an exchange layout: the slices' launches run side by side with RCCL's kernels, which wait for a slot of
             // their own as long as persistent workgroups hold every CU (R-MAT-26 through the exchange at world size 1: 1.86 -> 1.97 ms
@@ -1922,7 +1923,8 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             // persistent like phase 1: a slot per 128 KiB (f64) / 64 KiB (u32) of accumulators (GRAPHTAP_PB_PERSIST)
             // -- built, measured, OFF (GRAPHTAP_PB_PERSIST=2 / 3 switches it on): the counter closes phase 2's dispatch gaps too (busy integral
             // 91 -> 95 % of the launch) and its workgroups stream that much slower -- phase 2 runs at its mix's HBM rate either way
-            static const bool persist_forced = getenv("GRAPHTAP_PB_PERSIST") && (atoi(getenv("GRAPHTAP_PB_PERSIST")) & 2) != 0;
+            const char *pe = getenv("GRAPHTAP_PB_PERSIST");
+            const bool persist_forced = pe && (atoi(pe) & 2) != 0;
             const uint32_t slots = (uint32_t)pb->ncu * (sizeof(T) == 8 ? 1u : 2u);
             const bool persist = GT_P2_PERSIST != 0 && persist_forced && pb->p1_queue && slots && nw > slots;
             uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
@@ -2006,6 +2008,10 @@ extern "C" int gt_graph_hybrid_stats(const gt_graph *g, uint64_t *out4, int rese
     GT_HIP(hipMemcpy(out4, g->pb->hy_stat, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) GT_HIP(hipMemset(g->pb->hy_stat, 0, 4 * sizeof(unsigned long long)));
     return GT_OK;
+}
+// launches of the persistent phase 1 on this graph so far, both builds (diagnostic: the tests make sure the form they compare did run)
+extern "C" uint64_t gt_graph_persistent_launches(const gt_graph *g) {
+    return g ? (uint64_t)(g->pb ? g->pb->p1_seq : 0) + (uint64_t)(g->pb_wide ? g->pb_wide->p1_seq : 0) : 0;
 }
 uint32_t gt_pb_parts(const gt_graph *g) { return g->pb && !g->pb->work_part.empty() ? (uint32_t)g->pb->work_part.size() - 1 : 1; }
 const uint32_t *gt_pb_split_bins_part(const gt_graph *g, uint32_t k, uint32_t *n) {   // the split bins of part k of the phase-2 work list

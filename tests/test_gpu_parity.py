@@ -1140,6 +1140,33 @@ def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatc
     G.free(); ref["graph"].close(); want["graph"].close()
 
 
+def test_persistent_phase1_equals_the_dispatched_form(gt, O, monkeypatch):
+    """Phase 1 as persistent workgroups drawing chunks from a counter (pb.hip, k_pb_scatter `queue`; round 4) against one workgroup per
+    chunk: the same chunks, the same arithmetic inside each -- ranks BIT FOR BIT equal, with f64 messages (the narrow build's f64 kernel)
+    and with f32 messages on the wide build; each against the oracle as well. GRAPHTAP_PB_PERSIST is read per launch, and the
+    graph counts its persistent launches, so the test knows that both forms ran."""
+    from graphtap_amd.rmat import rmat_edges
+    L = gt._lib.lib(); L.gt_graph_persistent_launches.restype = C.c_uint64; L.gt_graph_persistent_launches.argtypes = [C.c_void_p]
+    scale, nv = 20, 1 << 20
+    e = rmat_edges(scale, 16, 9)
+    ref = O.run_app("pr", e, nv, iters=10)
+    for opts in (gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB), gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, wide_windows=1)):
+        ranks = {}
+        for mode in ("0", None):
+            if mode is None: monkeypatch.delenv("GRAPHTAP_PB_PERSIST", raising=False)
+            else: monkeypatch.setenv("GRAPHTAP_PB_PERSIST", mode)
+            G = gt.Graph(options=opts); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+            V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+            P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(10)
+            ranks[mode] = P.V["rank"].copy()
+            n = L.gt_graph_persistent_launches(G._h)
+            assert (n == 0) if mode == "0" else (n >= 10), (mode, n)
+            assert (np.abs(ranks[mode] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
+            P.free(); V.free(); G.free()
+        assert (ranks["0"] == ranks[None]).all()
+    ref["graph"].close()
+
+
 @pytest.mark.parametrize("hub_deg", [None, "2", "1000000"])
 def test_wide_build_gives_the_same_results(gt, O, hub_deg, known_answers, monkeypatch):
     """The WIDE propagation-blocking build (pb.hip, gt_pb::wide; round 4): windows of 32 766 / 32 768 slots -- pairs of the layout's
