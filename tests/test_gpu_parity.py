@@ -1142,9 +1142,10 @@ def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatc
 
 def test_persistent_phase1_equals_the_dispatched_form(gt, O, monkeypatch):
     """Phase 1 as persistent workgroups drawing chunks from a counter (pb.hip, k_pb_scatter `queue`; round 4) against one workgroup per
-    chunk: the same chunks, the same arithmetic inside each -- ranks BIT FOR BIT equal, with f64 messages (the narrow build's f64 kernel)
-    and with f32 messages on the wide build; each against the oracle as well. GRAPHTAP_PB_PERSIST is read per launch, and the
-    graph counts its persistent launches, so the test knows that both forms ran."""
+    chunk: the same chunks, the same arithmetic inside each -- the value stream is the same bit for bit; the ranks agree to 1e-12
+    relative (phase 2 adds the partial sums with LDS atomics in f64, whose order no two runs share: 1e-15 per sum), with f64
+    messages (the narrow build's f64 kernel) and with f32 messages on the wide build; each against the oracle as well.
+    GRAPHTAP_PB_PERSIST is read per launch, and the graph counts its persistent launches, so the test knows that both forms ran."""
     from graphtap_amd.rmat import rmat_edges
     L = gt._lib.lib(); L.gt_graph_persistent_launches.restype = C.c_uint64; L.gt_graph_persistent_launches.argtypes = [C.c_void_p]
     scale, nv = 20, 1 << 20
@@ -1163,7 +1164,7 @@ def test_persistent_phase1_equals_the_dispatched_form(gt, O, monkeypatch):
             assert (n == 0) if mode == "0" else (n >= 10), (mode, n)
             assert (np.abs(ranks[mode] - ref["rank"]) / ref["rank"]).max() < PR_RTOL
             P.free(); V.free(); G.free()
-        assert (ranks["0"] == ranks[None]).all()
+        assert (np.abs(ranks["0"] - ranks[None]) / ranks[None]).max() < 1e-12
     ref["graph"].close()
 
 
