@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                                                            const C4 *__restrict__ LCOL4, const WQ<WTy> *__restrict__ WT4,
                                                            const uint32_t *__restrict__ KSTART, const GroupRec *__restrict__ G,
                                                            const TX *__restrict__ x, TV *__restrict__ VAL, uint32_t *__restrict__ chunk_active,
-                                                           const uint32_t *__restrict__ launch_order, uint32_t chunk0, uint32_t dense_end,
+                                                           const gt_u32x4 *__restrict__ ldesc, uint32_t chunk0, uint32_t dense_end,
                                                            const uint8_t *__restrict__ win_mode, uint32_t *__restrict__ queue, uint32_t nlaunch) {
     static_assert(W + 1 == WS, "dense and sparse chunks share one LDS window");
     // the WIDE build (gt_pb::wide): windows of 2 W / 2 WS slots, 15 column bits, run heads as a mask in the group record
@@ -837,6 +837,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #endif
     constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
     __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 8];
+#ifndef GT_P1_PERSIST_ALL
+#define GT_P1_PERSIST_ALL 0
+#endif
+    // PERSISTENT form (queue != nullptr; below): compiled in only where it is used -- see the loop at the end of the kernel
+    constexpr bool CAN_PERSIST = GT_P1_PERSIST_ALL != 0 || (!IS_MIN && (WIDE || sizeof(TV) == 8));
     // one chunk: position bi of the launch = chunk c (largest chunks first, see gt_pb_build), its entry range [v0, v1) and first column
     auto chunk = [&](const uint32_t bi, const uint32_t c, const uint32_t v0c, const uint32_t v1c, const uint32_t col0) {
     const uint32_t q0c = v0c >> 2, q1c = v1c >> 2;   // the chunk's quad range (multiples of 64)
@@ -844,6 +849,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // cost a drain of the 64-KiB workgroups in between
     const bool sparse = col0 >= dense_end;
 #ifdef GT_EXP_TRACE
+    uint32_t trace_out = 0;
     if (threadIdx.x == 0 && bi < 16384) {
         gt_trace_p1[4 * bi] = wall_clock64(); gt_trace_p1[4 * bi + 2] = ((unsigned long long)c << 32) | (q1c - q0c);
         gt_trace_p1[4 * bi + 3] = gt_trace_where();
@@ -990,6 +996,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             // constants come off the group record with scalar reads: dword 0 for the run the group starts in, dword j for the run
             // of its j-th head (lane j of gw holds dword j), KSTART for heads beyond the sixth.
             const uint32_t nout = (uint32_t)(__popcll((unsigned long long)E0) + __popcll((unsigned long long)E1) + __popcll((unsigned long long)E2) + __popcll((unsigned long long)E3));
+#ifdef GT_EXP_TRACE
+            trace_out += nout;
+#endif
             const uint32_t d0 = __builtin_amdgcn_readlane(gw[u], 0);
             const uint64_t Hb = WIDE ? HbG : __ballot(head);
 #ifdef GT_EXP_P1_NO_STORES   // timing experiment (wrong results): the outputs are staged and not stored
@@ -1022,7 +1031,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         for (int u = 0; u < U; u++) { lc[u] = nlc[u]; gw[u] = ngw[u]; w[u] = nw[u]; }
     }
 #ifdef GT_EXP_TRACE
-    if (lane == 0 && bi < 16384) atomicMax(&gt_trace_p1[4 * bi + 1], (unsigned long long)wall_clock64());
+    if (lane == 0 && bi < 16384) {
+        atomicMax(&gt_trace_p1[4 * bi + 1], (unsigned long long)wall_clock64());
+        atomicAdd(&gt_trace_p1[4 * bi + 3], (unsigned long long)(sparse ? 0u : trace_out) << 36);   // the chunk's outputs (a sparse chunk: one per entry)
+    }
 #endif
     };
     // PERSISTENT form (queue != nullptr): as many workgroups as the chip holds at once, each drawing the next position of the launch
@@ -1035,20 +1047,17 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // words of wave 0's staging row, which wave 0 writes again only behind the barrier that follows the staging of the window)
     volatile uint32_t *mb = reinterpret_cast<volatile uint32_t *>(&stage[0][0]);
     // Thread 0 draws a position and loads that chunk's description when the workgroup NEEDS it. (Drawing the next one at the START of
-    // the current chunk -- the atomic and the three dependent loads, ~3 us, in flight while the chunk runs -- was measured: phase 1
+    // the current chunk -- the atomic and the dependent loads, ~3 us, in flight while the chunk runs -- was measured: phase 1
     // 0.968 -> 1.015 ms, six rounds of A/B. A workgroup that has committed itself one chunk ahead is no longer the first free one
-    // when that chunk's turn comes: the list scheduling that persistence buys is lost again.)
+    // when that chunk's turn comes: the list scheduling that persistence buys is lost again. Drawing when wave 0 enters its LAST
+    // trip of the chunk, a few microseconds ahead: 0.961 -> 0.978 ms, six rounds -- profiles/r04/ab_first_last_and_persistent.txt (10).)
     // Compiled in only where it is used: the kernels that fit ONE workgroup per CU (the wide window, f64 messages), where nothing else
     // covers a dispatch gap. The two-per-CU kernels lose with it (f32 messages on the narrow build: R-MAT-22 460 -> 425 GTEPS, R-MAT-24
-    // 652 -> 640 -- a draw costs an atomic and dependent loads that a 10-us chunk does not amortise) and so do the min programs (see
-    // pb_run); GT_P1_PERSIST_ALL=1 compiles it into every instantiation (A/B with GRAPHTAP_PB_PERSIST=1).
-#ifndef GT_P1_PERSIST_ALL
-#define GT_P1_PERSIST_ALL 0
-#endif
-    constexpr bool CAN_PERSIST = GT_P1_PERSIST_ALL != 0 || (!IS_MIN && (WIDE || sizeof(TV) == 8));
+    // 652 -> 640, R-MAT-25 715 -> 690) and so do the min programs (see pb_run); GT_P1_PERSIST_ALL=1 compiles it into every
+    // instantiation (A/B with GRAPHTAP_PB_PERSIST=1). A position's description is ONE 16-byte load (ldesc, in launch order).
     if constexpr (!CAN_PERSIST) {
-        const uint32_t c = launch_order[chunk0 + blockIdx.x];
-        chunk(blockIdx.x, c, cv0[c], cv1[c], ccol0[c]);
+        const gt_u32x4 d = ldesc[chunk0 + blockIdx.x];
+        chunk(blockIdx.x, d.x, d.y, d.z, d.w);
     } else
     for (;;) {
         uint32_t bi, c, v0c, v1c, col0;
@@ -1058,14 +1067,15 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
                 const uint32_t nb = atomicAdd(queue, 1u);
                 if (nb == nlaunch + gridDim.x - 1) atomicExch(queue, 0u);
                 mb[0] = nb;
-                if (nb < nlaunch) { const uint32_t nc = launch_order[chunk0 + nb]; mb[1] = nc; mb[2] = cv0[nc]; mb[3] = cv1[nc]; mb[4] = ccol0[nc]; }
+                if (nb < nlaunch) { const gt_u32x4 d = ldesc[chunk0 + nb]; mb[1] = d.x; mb[2] = d.y; mb[3] = d.z; mb[4] = d.w; }
             }
             __syncthreads();
             bi = mb[0];
             if (bi >= nlaunch) break;
             c = mb[1]; v0c = mb[2]; v1c = mb[3]; col0 = mb[4];
         } else {
-            bi = blockIdx.x; c = launch_order[chunk0 + bi]; v0c = cv0[c]; v1c = cv1[c]; col0 = ccol0[c];
+            const gt_u32x4 d = ldesc[chunk0 + blockIdx.x];
+            bi = blockIdx.x; c = d.x; v0c = d.y; v1c = d.z; col0 = d.w;
         }
         chunk(bi, c, v0c, v1c, col0);
         if (!queue) break;
@@ -1263,6 +1273,7 @@ struct gt_pb {
     uint32_t val_allocs = 0;   // allocations of VAL so far (gt_exec_stats.allocs_in_execute counts those made inside execute())
     uint32_t *chunk_active = nullptr, *active_prefix = nullptr;   // activity filtering of the min programs
     uint32_t *launch_order = nullptr;   // [nchunks] phase-1 workgroup -> chunk: inside every slice (and kind), largest chunk first
+    uint32_t *ldesc = nullptr;          // [nchunks][4] the same order with each chunk's description: {chunk, cv0, cv1, ccol0}
     // persistent phase 1 (k_pb_scatter, `queue`): a ring of zeroed counters, one per launch in flight (slices of an exchange layout run
     // side by side on streams of their own), and the CUs of the device
     uint32_t *p1_queue = nullptr; uint32_t p1_seq = 0; int ncu = 0;
@@ -1296,7 +1307,7 @@ struct gt_pb {
 
 void gt_pb_free(gt_pb *pb) {
     if (!pb) return;
-    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->p1_queue, pb->bin_single, pb->split_bins,
+    void *ptrs[] = {pb->cv0, pb->cv1, pb->ccol0, pb->LCOL, pb->LROW, pb->WT, pb->KSTART, pb->G, pb->work, pb->VAL, pb->chunk_active, pb->active_prefix, pb->launch_order, pb->ldesc, pb->p1_queue, pb->bin_single, pb->split_bins,
                     pb->win_entries, pb->xdeg, pb->win_act, pb->win_mode, pb->hy_col, pb->hy_val, pb->hy_deg, pb->hy_long, pb->hy_cnt, pb->hy_stat, pb->hy_cand};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : pb->pt_ev) (void)hipEventDestroy(e);
@@ -1791,6 +1802,12 @@ static int pb_build_impl(gt_graph *g, bool wide, gt_pb **out) {
         }
         PB_MALLOC(pb->launch_order, (uint64_t)std::max(nchunks, 1u) * 4);
         PB_HIP(hipMemcpy(pb->launch_order, ord.data(), (uint64_t)nchunks * 4, hipMemcpyHostToDevice));
+        {   // what a phase-1 workgroup needs to know about position i of the launch, in one 16-byte load: {chunk, cv0, cv1, ccol0}
+            std::vector<uint32_t> desc((size_t)std::max(nchunks, 1u) * 4, 0);
+            for (uint32_t i = 0; i < nchunks; i++) { const uint32_t c = ord[i]; desc[4 * (size_t)i] = c; desc[4 * (size_t)i + 1] = a[c]; desc[4 * (size_t)i + 2] = b[c]; desc[4 * (size_t)i + 3] = hcol[c]; }
+            PB_MALLOC(pb->ldesc, desc.size() * 4);
+            PB_HIP(hipMemcpy(pb->ldesc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
+        }
         PB_MALLOC(pb->p1_queue, P1_QUEUES * 4); PB_HIP(hipMemset(pb->p1_queue, 0, P1_QUEUES * 4));
         { int dev = 0; hipDeviceProp_t prop; PB_HIP(hipGetDevice(&dev)); PB_HIP(hipGetDeviceProperties(&prop, dev)); pb->ncu = prop.multiProcessorCount; }
     }
@@ -1903,7 +1920,7 @@ static int pb_run(const gt_graph *g, gt_pb *pb, const TX *x, T *y, hipStream_t s
             uint32_t *q = persist ? pb->p1_queue + (pb->p1_seq++ % P1_QUEUES) : nullptr;
             k_pb_scatter<T, TV, TX, WEIGHTED, IS_MIN, WTy, WIDE><<<persist ? slots : c1 - c0, P1_THREADS, 0, s>>>(
                 pb->cv0, pb->cv1, pb->ccol0, g->x_len, (const C4 *)pb->LCOL, (const WQ<WTy> *)pb->WT, pb->KSTART,
-                (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, pb->launch_order, c0, g->ndw * W, win_mode, q, c1 - c0);
+                (const GroupRec *)pb->G, x, (TV *)pb->VAL, ca, (const gt_u32x4 *)pb->ldesc, c0, g->ndw * W, win_mode, q, c1 - c0);
         };
         // one launch: [regular rows: dense, sparse][source rows: dense, sparse]; computation filtering (TCSC_CF) leaves the
         // source rows' chunks out of every iteration but the last

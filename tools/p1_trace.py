@@ -32,6 +32,7 @@ TICK = 0.01   # us per tick (100 MHz)
 
 
 def cu_of(where):
+    where = where & np.uint64((1 << 36) - 1)   # (above: the chunk's outputs, phase 1)
     hw = where & 0xFFFFFFFF; xcc = (where >> 32) & 0xF
     return (xcc.astype(np.int64) << 16) | ((hw >> 8) & 0xF).astype(np.int64) | (((hw >> 12) & 0xF).astype(np.int64) << 4)   # XCC, cu_id, sh/se
 
@@ -75,6 +76,26 @@ def report(name, start, end, where, size, extra=None):
 
 
 w1 = p1.reshape(-1, 4)
+# a duration model of a phase-1 chunk: a * entries + b * outputs + c (least squares over the launch), and what list scheduling
+# in the order of THAT estimate would give against the order by entries the library uses
+ok1 = w1[:, 0] > 0
+E1 = ((w1[ok1, 2] & np.uint64(0xFFFFFFFF)) * np.uint64(4)).astype(np.float64); D1 = (w1[ok1, 1].astype(np.int64) - w1[ok1, 0].astype(np.int64)) * TICK
+S1 = (w1[ok1, 3] >> np.uint64(36)).astype(np.float64); S1 = np.where(S1 == 0, E1, S1)
+A = np.stack([E1, S1, np.ones_like(E1)], 1); coef, *_ = np.linalg.lstsq(A, D1, rcond=None)
+pred = A @ coef
+print("== phase-1 chunk duration ~ %.4f us per 1000 entries + %.4f us per 1000 outputs + %.2f us; residual rms %.1f us (median duration %.1f)" % (coef[0] * 1e3, coef[1] * 1e3, coef[2], np.sqrt(((pred - D1) ** 2).mean()), np.median(D1)))
+
+
+def makespan(order, dur, m=256):
+    import heapq
+    h = [0.0] * m
+    for i in order:
+        t = heapq.heappop(h); heapq.heappush(h, t + dur[i])
+    return max(h)
+
+
+print("   list scheduling of the measured durations on 256 slots: in the order of the entries %.1f us, of the estimate %.1f us, of the durations themselves %.1f us, sum/256 = %.1f us" % (
+    makespan(np.argsort(-E1), D1), makespan(np.argsort(-pred), D1), makespan(np.argsort(-D1), D1), D1.sum() / 256))
 report("phase 1 (k_pb_scatter)", w1[:, 0], w1[:, 1], w1[:, 3], (w1[:, 2] & np.uint64(0xFFFFFFFF)) * np.uint64(4))
 w2 = p2.reshape(-1, 8)
 
