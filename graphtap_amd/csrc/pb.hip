@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256) k_hybrid_long(const uint32_t *__restrict_
 }
 
 #ifdef GT_EXP_TRACE   // timing experiment: per-workgroup start / end (100-MHz wall clock), what it worked on and where it ran (tools/p1_trace.py)
-__device__ unsigned long long gt_trace_p1[4 * 16384], gt_trace_p2[4 * 16384];
+__device__ unsigned long long gt_trace_p1[4 * 16384], gt_trace_p2[4 * 16384], gt_trace_w[16 * 8192];   // (gt_trace_w: the end of each of a phase-1 workgroup's 16 waves)
 __device__ __forceinline__ unsigned long long gt_trace_where() {
     return ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
 }
@@ -836,7 +836,16 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #define GT_P1_PERSIST_DEFAULT 1
 #endif
     constexpr bool STAGED = !IS_MIN || GT_P1_STAGE_MIN != 0;
-    __shared__ TV stage[STAGED ? P1_THREADS / 64 : 1][STAGED ? 256 : 8];
+    // DYNAMIC TRIPS (the wide kernel): a wave takes its next trip of U groups from a counter of the workgroup instead of every 16th
+    // one. The 16 waves of a workgroup are four per SIMD, and a SIMD's arbiter prefers its OLDEST wave: with equal shares waves 0-3
+    // are done at 75 % of the chunk's duration, 4-7 at 81 %, 8-11 at 89 % (tools/p1_trace.py, workgroup_timeline_waves.txt) -- 15 % of
+    // the wave-time of phase 1 idles in that drain, once per chunk. The counter lives in a seventeenth staging row (the wide kernel has
+    // 16 KiB of LDS to spare; the 64-KiB-window and f64 kernels have none).
+#ifndef GT_P1_DYN_TRIPS
+#define GT_P1_DYN_TRIPS 1
+#endif
+    constexpr bool DYN = GT_P1_DYN_TRIPS != 0 && WIDE && STAGED;
+    __shared__ TV stage[STAGED ? P1_THREADS / 64 + (DYN ? 1 : 0) : 1][STAGED ? 256 : 8];
 #ifndef GT_P1_PERSIST_ALL
 #define GT_P1_PERSIST_ALL 0
 #endif
@@ -850,9 +859,9 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     const bool sparse = col0 >= dense_end;
 #ifdef GT_EXP_TRACE
     uint32_t trace_out = 0;
-    if (threadIdx.x == 0 && bi < 16384) {
-        gt_trace_p1[4 * bi] = wall_clock64(); gt_trace_p1[4 * bi + 2] = ((unsigned long long)c << 32) | (q1c - q0c);
-        gt_trace_p1[4 * bi + 3] = gt_trace_where();
+    if (threadIdx.x == 0 && bi < 8192) {
+        gt_trace_p1[8 * bi] = wall_clock64(); gt_trace_p1[8 * bi + 2] = ((unsigned long long)c << 32) | (q1c - q0c);
+        gt_trace_p1[8 * bi + 3] = gt_trace_where();
     }
 #endif
     if constexpr (IS_MIN) {
@@ -894,14 +903,22 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
             if constexpr (WEIGHTED) ow[u] = ld_stream<NT_P1>(WT4 + q); else ow[u] = WQ<WTy>{{0, 0, 0, 0}};
         }
     };
-    uint32_t g0 = (q0c >> 6) + wave * U;
+    const uint32_t gb = q0c >> 6;
+    uint32_t g0 = gb + wave * U;   // the first trip: the wave's own (its loads go out before the window is staged)
     if (g0 < gend) issue_loads(g0, lc, gw, w);
+    uint32_t *tctr = reinterpret_cast<uint32_t *>(&stage[DYN ? NW : 0][0]);
+    if constexpr (DYN) { if (threadIdx.x == 0) *tctr = NW; }   // (every wave of the previous chunk is behind a barrier; the first draw is behind the next one)
     if constexpr (PREFETCH) {
         if (!stage_window<TV, TX, IS_MIN, P1_THREADS, WIN>(xwin, x, col0, wn, chunk_active, c)) return;
         __syncthreads();
+#ifdef GT_EXP_TRACE
+        if (threadIdx.x == 0 && bi < 8192) gt_trace_p1[8 * bi + 4] = wall_clock64();   // the window is staged
+#endif
     }
     while (g0 < gend) {
-        const uint32_t gn = g0 + NW * U;
+        uint32_t gn;
+        if constexpr (DYN) { uint32_t t = 0; if (lane == 0) t = atomicAdd(tctr, 1u); gn = gb + (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * U; }
+        else gn = g0 + NW * U;
         if (gn < gend) issue_loads(gn, nlc, ngw, nw);
         // (Round 4, wide build: gathering the messages of all the trip's groups first, and scanning the carries of all of them in one batch
         // -- N dependency chains side by side instead of one after the other -- were both built and measured: nothing / +6 % in phase 1,
@@ -1031,9 +1048,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         for (int u = 0; u < U; u++) { lc[u] = nlc[u]; gw[u] = ngw[u]; w[u] = nw[u]; }
     }
 #ifdef GT_EXP_TRACE
-    if (lane == 0 && bi < 16384) {
-        atomicMax(&gt_trace_p1[4 * bi + 1], (unsigned long long)wall_clock64());
-        atomicAdd(&gt_trace_p1[4 * bi + 3], (unsigned long long)(sparse ? 0u : trace_out) << 36);   // the chunk's outputs (a sparse chunk: one per entry)
+    if (lane == 0 && bi < 8192) {
+        atomicMax(&gt_trace_p1[8 * bi + 1], (unsigned long long)wall_clock64());
+        atomicAdd(&gt_trace_p1[8 * bi + 3], (unsigned long long)(sparse ? 0u : trace_out) << 36);   // the chunk's outputs (a sparse chunk: one per entry)
+        if (threadIdx.x == 0) gt_trace_p1[8 * bi + 5] = wall_clock64();   // wave 0 is done
+        gt_trace_w[16 * bi + wave] = wall_clock64();
     }
 #endif
     };
@@ -1064,10 +1083,16 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         if (queue) {
             __syncthreads();   // every wave is done with the window and with its staging row
             if (threadIdx.x == 0) {
+#ifdef GT_EXP_TRACE
+                const unsigned long long t_b1 = wall_clock64();   // every wave of the previous chunk has arrived
+#endif
                 const uint32_t nb = atomicAdd(queue, 1u);
                 if (nb == nlaunch + gridDim.x - 1) atomicExch(queue, 0u);
                 mb[0] = nb;
                 if (nb < nlaunch) { const gt_u32x4 d = ldesc[chunk0 + nb]; mb[1] = d.x; mb[2] = d.y; mb[3] = d.z; mb[4] = d.w; }
+#ifdef GT_EXP_TRACE
+                if (nb < nlaunch && nb < 8192) { gt_trace_p1[8 * nb + 6] = t_b1; gt_trace_p1[8 * nb + 7] = wall_clock64(); }   // ... and the draw is back
+#endif
             }
             __syncthreads();
             bi = mb[0];
@@ -1242,6 +1267,11 @@ extern "C" int gt_exp_trace_dump(unsigned long long *p1, unsigned long long *p2)
     GT_HIP(hipDeviceSynchronize());
     GT_HIP(hipMemcpyFromSymbol(p1, HIP_SYMBOL(gt_trace_p1), sizeof(unsigned long long) * 4 * 16384));
     GT_HIP(hipMemcpyFromSymbol(p2, HIP_SYMBOL(gt_trace_p2), sizeof(unsigned long long) * 4 * 16384));
+    return GT_OK;
+}
+extern "C" int gt_exp_trace_dump_waves(unsigned long long *w) {   // 16 x 8192 words
+    GT_HIP(hipDeviceSynchronize());
+    GT_HIP(hipMemcpyFromSymbol(w, HIP_SYMBOL(gt_trace_w), sizeof(unsigned long long) * 16 * 8192));
     return GT_OK;
 }
 #endif

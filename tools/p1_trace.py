@@ -75,7 +75,7 @@ def report(name, start, end, where, size, extra=None):
     if extra is not None: extra(ok, s, e, t0)
 
 
-w1 = p1.reshape(-1, 4)
+w1 = p1.reshape(-1, 8)
 # a duration model of a phase-1 chunk: a * entries + b * outputs + c (least squares over the launch), and what list scheduling
 # in the order of THAT estimate would give against the order by entries the library uses
 ok1 = w1[:, 0] > 0
@@ -96,6 +96,25 @@ def makespan(order, dur, m=256):
 
 print("   list scheduling of the measured durations on 256 slots: in the order of the entries %.1f us, of the estimate %.1f us, of the durations themselves %.1f us, sum/256 = %.1f us" % (
     makespan(np.argsort(-E1), D1), makespan(np.argsort(-pred), D1), makespan(np.argsort(-D1), D1), D1.sum() / 256))
+# where the time between two chunks of a workgroup goes (persistent form): barrier after the last wave -> draw back -> chunk entry -> window staged
+if (w1[ok1, 6] > 0).any():
+    t = w1[ok1].astype(np.int64); sel = t[:, 6] > 0
+    t = t[sel]
+    print("== between two chunks of a persistent workgroup (medians, us): draw (atomic + description) %.2f; to the chunk's entry %.2f; staging the window (incl. the first trip's loads) %.2f; wave 0 done -> last wave done %.2f" % (
+        np.median(t[:, 7] - t[:, 6]) * TICK, np.median(t[:, 0] - t[:, 7]) * TICK, np.median(t[:, 4] - t[:, 0]) * TICK, np.median(t[:, 1] - t[:, 5]) * TICK))
+    # the same per CU: previous chunk's last wave done -> this chunk's barrier passed needs the CU mapping; gaps are reported below
+if hasattr(raw, "gt_exp_trace_dump_waves"):   # the 16 waves of a phase-1 workgroup: when each was done
+    ww = np.zeros(16 * 8192, np.uint64); assert raw.gt_exp_trace_dump_waves(ww.ctypes.data_as(C.c_void_p)) == 0
+    ww = ww.reshape(-1, 16)[: w1.shape[0]][ok1[: 8192]].astype(np.int64)
+    good = (ww > 0).all(1); ww = ww[good]
+    st = w1[ok1][good][:, 0].astype(np.int64)
+    rel = (ww - st[:, None]) * TICK                       # each wave's end, from the chunk's entry
+    dur = rel.max(1)
+    big = dur > np.percentile(dur, 50)
+    print("== the 16 waves of a workgroup (chunks above the median duration, %d of them): last wave done at %.1f us (median); the others, sorted, are done at %s %% of it" % (
+        big.sum(), np.median(dur[big]), np.round(np.median(np.sort(rel[big], 1) / dur[big][:, None], 0) * 100).astype(int).tolist()))
+    print("   by wave index (median end / last end, %%): %s" % np.round(np.median(rel[big] / dur[big][:, None], 0) * 100).astype(int).tolist())
+    print("   wave-time lost to the drain: %.1f %% of the workgroups' wave-time" % (100 * (dur[:, None] - rel).sum() / (16 * dur.sum())))
 report("phase 1 (k_pb_scatter)", w1[:, 0], w1[:, 1], w1[:, 3], (w1[:, 2] & np.uint64(0xFFFFFFFF)) * np.uint64(4))
 w2 = p2.reshape(-1, 8)
 
