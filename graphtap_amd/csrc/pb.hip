@@ -915,7 +915,24 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         if (threadIdx.x == 0 && bi < 8192) gt_trace_p1[8 * bi + 4] = wall_clock64();   // the window is staged
 #endif
     }
+    // ROTATING PRIORITY (the kernels without LDS to spare for a trip counter): the waves of a SIMD take turns at its priority, one trip
+    // each (s_setprio; waves 4s .. 4s+3 of a workgroup are the s-th waves of the four SIMDs) -- the arbiter then has no favourite.
+    // f64 messages, R-MAT-26: waves done at 73 / 80 / 88 / 99 % of a chunk's duration -> 93-100 %, wave-time lost to the drain
+    // 16.9 -> 8.0 %, phase 1 1.372 -> 1.312 ms (four rounds of A/B, profiles/r04/ab_rotating_priority.txt); f32 messages on the narrow
+    // build R-MAT-24 +3 %, R-MAT-22 +-0; the min programs +-1 %.
+#ifndef GT_P1_ROTATE_PRIO
+#define GT_P1_ROTATE_PRIO 1
+#endif
+    uint32_t trip_no = wave >> 2;
     while (g0 < gend) {
+        if constexpr (GT_P1_ROTATE_PRIO != 0 && !DYN) {
+            switch (trip_no++ & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         uint32_t gn;
         if constexpr (DYN) { uint32_t t = 0; if (lane == 0) t = atomicAdd(tctr, 1u); gn = gb + (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * U; }
         else gn = g0 + NW * U;
@@ -1126,7 +1143,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
                                                           uint32_t *__restrict__ queue, uint32_t nlaunch) {
     __shared__ T acc[R + 1];   // row R: the dummy row every pad output targets
     __shared__ unsigned wsum[P2_THREADS / 64];
-    __shared__ uint32_t next_bi;
+    __shared__ uint32_t next_bi, p2_trip;
     auto item = [&](const uint32_t bi) {   // one entry of the work list: position bi of the launch
     const BinWork wk = work[bi];
     if (active_prefix && active_prefix[wk.c_hi + 1] == active_prefix[wk.c_lo]) return;   // no active chunk feeds this slice
@@ -1141,12 +1158,49 @@ __global__ void __launch_bounds__(P2_THREADS) k_pb_gather(const BinWork *__restr
 #define GT_TRACE_P2_END() do { } while (0)
 #endif
     for (uint32_t i = threadIdx.x; i <= R; i += P2_THREADS) acc[i] = neutral;
+#ifndef GT_P2_DYN
+#define GT_P2_DYN 1
+#endif
+    if (GT_P2_DYN && threadIdx.x == 0) p2_trip = P2_THREADS / 64;   // the first trip of a wave is its own
     __syncthreads();
     // 4 consecutive entries per lane per load (16-byte VAL loads for f32/u32 streams, 2 x 16 B for f64;
     // 8-byte LROW loads), P2_U quads in flight per lane (one workgroup per CU: the loads in flight have to cover
     // the HBM latency by themselves); every range is a multiple of 4 (padded runs).
     const uint32_t qb = wk.k1 >> 2;
+#if GT_P2_DYN
+    // DYNAMIC TRIPS, as in phase 1's wide kernel (k_pb_scatter, DYN): a wave takes its next P2_U x 64 quads from a counter of the
+    // workgroup -- with equal shares the SIMD's oldest waves are done long before its youngest
+    {
+        const uint32_t lane = threadIdx.x & 63, q0 = wk.k0 >> 2;
+        constexpr uint32_t TQ = P2_U * 64;   // quads of a wave's trip
+        uint32_t t = threadIdx.x >> 6;
+        for (;;) {
+            const uint32_t base = q0 + t * TQ;
+            if (base >= qb) break;
+            uint32_t tn = 0;
+            if (lane == 0) tn = atomicAdd(&p2_trip, 1u);
+            if (base + TQ <= qb) {
+                C4 r[P2_U]; V4<TV> a[P2_U];
+#pragma unroll
+                for (int u = 0; u < P2_U; u++) { r[u] = ld_stream<NT_P2>(LROW4 + (base + u * 64 + lane)); a[u] = ld_stream<NT_P2>(VAL4 + (base + u * 64 + lane)); }
+#pragma unroll
+                for (int u = 0; u < P2_U; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r[u].c[j], (T)a[u].a[j]);
+            } else {
+                for (uint32_t qq = base + lane; qq < qb; qq += 64) {
+                    const C4 r0 = ld_stream<NT_P2>(LROW4 + qq); const V4<TV> a0 = ld_stream<NT_P2>(VAL4 + qq);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) lds_combine<T, IS_MIN>(acc, r0.c[j], (T)a0.a[j]);
+                }
+            }
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tn);
+        }
+    }
+    uint32_t q = qb;
+#else
     uint32_t q = (wk.k0 >> 2) + threadIdx.x;
+#endif
     for (; q + (P2_U - 1) * P2_THREADS < qb; q += P2_U * P2_THREADS) {
         C4 r[P2_U]; V4<TV> a[P2_U];
 #pragma unroll
