@@ -1503,14 +1503,15 @@ int gt_pb_build(gt_graph *g) {
     // gt_spmv) keep the narrow build (an f64 window of that width would be 256 KiB). GRAPHTAP_PB_WIDE=0 / 1: never / for every graph
     // without an exchange layout.
     const char *ew = gt_cfg(g, "GRAPHTAP_PB_WIDE");
-    // ... by default only from ~0.8 G stored entries: measured by scale (PageRank f32 messages, narrow -> wide). Workgroups dispatched
+    // ... by default only from ~0.47 G stored entries (R-MAT-25): measured by scale (PageRank f32 messages, narrow -> wide). Workgroups dispatched
     // per chunk (profiles/r04/ab_wide_windows_by_scale.txt): R-MAT-22 458 -> 423 GTEPS, 23: 536 -> 547, 24: 662 -> 633, 25: 716 -> 698,
     // 26: 686 -> 710 -- phase 1 pays its +18 % everywhere, phase 2's -20 % outweighs it only on the largest graph. With the persistent
     // phase 1 (profiles/r04/ab_recheck_after_register_fix.txt): R-MAT-20 174 -> 157, 21: 281 -> 273, 22: 422 -> 418, 24: 630 -> 633,
-    // 25: 715 -> 707 (ab_recheck_after_register_fix.txt, third block).
+    // 25: 715 -> 707 (ab_recheck_after_register_fix.txt, third block). With dynamic trips in the wide kernel and the rotating priority in
+    // the narrow one (ab_wide_by_scale_final.txt): R-MAT-22 462 -> 425, 23: 532 -> 569, 24: 680 -> 672, 25: 722 -> 751, 26: wide.
     // (An A/B in between had the wide build win from R-MAT-21 up -- against a narrow kernel that a doubled register count had cut to
     // one workgroup per CU; see k_pb_scatter, "ONE call site".)
-    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (3ull << 28));
+    const bool want = ew ? atoi(ew) != 0 : (g->spmv_variant == GT_SPMV_PB_F32MSG && g->info.nnz_local >= (7ull << 26));
     if (want && !g->pb_wide && !gt_has_exchange(g) && g->info.nnz_local) { gt_pb *pb = nullptr; int st = pb_build_impl(g, true, &pb); if (st != GT_OK) return st; g->pb_wide = pb; }
     return GT_OK;
 }

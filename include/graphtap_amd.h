@@ -240,7 +240,7 @@ typedef struct gt_graph_options {
     uint32_t exchange_hub_min; /* the same inside a block of the exchange layout; 0 unset: GRAPHTAP_EXCHANGE_HUB_MIN, default 8 */
     uint32_t chunk_log2;       /* log2 entries per phase-1 chunk; 0 unset: GRAPHTAP_PB_CH, default by size (<= 19) */
     int32_t wide_windows;      /* 1 always / 0 never: the WIDE propagation-blocking build beside the narrow one (gt_graph_has_wide_build);
-                                  -1 unset: GRAPHTAP_PB_WIDE, default for GT_SPMV_PB_F32MSG graphs of ~0.8 G entries and more on one rank */
+                                  -1 unset: GRAPHTAP_PB_WIDE, default for GT_SPMV_PB_F32MSG graphs of ~0.47 G entries (R-MAT-25) and more on one rank */
     uint32_t reserved[7];
 } gt_graph_options;
 typedef struct gt_program_options {
@@ -267,7 +267,7 @@ int gt_graph_build_opt(gt_graph **out, gt_dist *dist, const void *edges, uint64_
                        uint32_t num_vertices, const gt_graph_flags *flags, int rank, int nranks, const gt_graph_options *opt);
 int gt_graph_info_get(const gt_graph *g, gt_graph_info *info);
 /* 1 when the graph also carries the WIDE propagation-blocking build (windows of twice the width, used by SpMVs with 4-byte PageRank
- * messages; built for GT_SPMV_PB_F32MSG graphs of ~0.8 G entries and more on one rank, or on request: GRAPHTAP_PB_WIDE), else 0 */
+ * messages; built for GT_SPMV_PB_F32MSG graphs of ~0.47 G entries (R-MAT-25) and more on one rank, or on request: GRAPHTAP_PB_WIDE), else 0 */
 int gt_graph_has_wide_build(const gt_graph *g);
 /* Picks the SpMV implementation used by gt_spmv and by every program of this graph (default
  * GT_SPMV_PB; GT_SPMV_PB_F32MSG / GT_SPMV_EDGE when the environment has GRAPHTAP_SPMV=pb_f32msg / edge at build time). */

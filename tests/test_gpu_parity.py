@@ -1171,7 +1171,7 @@ def test_persistent_phase1_equals_the_dispatched_form(gt, O, monkeypatch):
 @pytest.mark.parametrize("hub_deg", [None, "2", "1000000"])
 def test_wide_build_gives_the_same_results(gt, O, hub_deg, known_answers, monkeypatch):
     """The WIDE propagation-blocking build (pb.hip, gt_pb::wide; round 4): windows of 32 766 / 32 768 slots -- pairs of the layout's
-    windows -- 15 column bits, the run heads as a mask in the group record. By default only graphs of ~0.8 G entries and more get it
+    windows -- 15 column bits, the run heads as a mask in the group record. By default only graphs of ~0.47 G entries and more get it
     (the full-size headline tests run on it); here GRAPHTAP_PB_WIDE=1 builds it for small and mid-size graphs: PageRank with f32
     messages against the reference's vectors and the oracle (fixed count, hand-stepped without the fused applicator, and converge
     mode -- which runs f64 messages on the NARROW build of the same graph), and -- the same switch sends the min programs
