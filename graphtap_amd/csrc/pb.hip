@@ -920,6 +920,10 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
     // f64 messages, R-MAT-26: waves done at 73 / 80 / 88 / 99 % of a chunk's duration -> 93-100 %, wave-time lost to the drain
     // 16.9 -> 8.0 %, phase 1 1.372 -> 1.312 ms (four rounds of A/B, profiles/r04/ab_rotating_priority.txt); f32 messages on the narrow
     // build R-MAT-24 +3 %, R-MAT-22 +-0; the min programs +-1 %.
+    // (The counter in HBM instead -- one per workgroup, a wave asking for the trip AFTER the next one while it works on the current one
+    // -- was built for these kernels and measured: f64 phase 1 1.30 -> 1.45 ms, the 64-KiB-window kernel +17 to +28 %: the returning
+    // atomic sits in the same in-order vmcnt queue as the loads and stores of the software pipeline, and waiting for it drains the
+    // queue. profiles/r04/ab_trip_counter_in_hbm_rejected.txt.)
 #ifndef GT_P1_ROTATE_PRIO
 #define GT_P1_ROTATE_PRIO 1
 #endif
