@@ -886,7 +886,13 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
         __syncthreads();
     }
     constexpr uint32_t NW = P1_THREADS / 64;
-    constexpr int U = 4;   // 256-entry groups in flight per wave (the wide build, one workgroup per CU: 4, 6 and 8 run alike)
+#ifndef GT_P1_U_WIDE
+#define GT_P1_U_WIDE 6
+#endif
+    // 256-entry groups per trip and wave. The wide kernel (one workgroup per CU, trips handed out dynamically): 6 -- phase 1 0.905 -> 0.886 ms
+    // against 4, 2: 0.978, 3: 0.927 (three rounds, profiles/r04/ab_trip_size.txt); the others 4 (the two-per-CU kernels must stay at
+    // <= 64 VGPRs; f64 messages: 4 and 6 run alike)
+    constexpr int U = WIDE ? GT_P1_U_WIDE : 4;
     const uint32_t gend = q1c >> 6;   // chunk ranges are multiples of 256 entries = 64 quads (k_align_chunks)
     const uint32_t *__restrict__ Gw = reinterpret_cast<const uint32_t *>(G);
     char *__restrict__ VALb = reinterpret_cast<char *>(VAL);
