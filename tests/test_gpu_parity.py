@@ -1140,6 +1140,32 @@ def test_handle_level_options_two_graphs_in_one_process_differ(gt, O, monkeypatc
     G.free(); ref["graph"].close(); want["graph"].close()
 
 
+def test_groups_whose_256_entries_all_end_a_stretch(gt, O):
+    """A permutation-like matrix with every column declared a hub (gt_graph_options.hub_min_degree = 1): every entry of a dense window
+    is the only one of its row there, so every 256-entry group of phase 1 has 256 outputs -- the staging row of a wave full to its
+    last entry, every lane storing four outputs, run constants changing inside groups. (Written for a trip counter that lived in that
+    last entry, round 4 -- measured slower than the rotating priority and never merged: DESIGN.md 4.1 item 5; the case stays.) PageRank, f64 and f32 messages
+    on the narrow and the wide build, against the oracle; plus a second graph with two entries per row and window, where stretches
+    of two alternate with the full groups."""
+    rng = np.random.default_rng(11)
+    nv = 1 << 17
+    for per_row in (1, 2):
+        src = np.concatenate([rng.permutation(nv) for _ in range(per_row)]).astype(np.uint32)
+        dst = np.tile(np.arange(nv, dtype=np.uint32), per_row)
+        if per_row == 2: src[nv:] = (src[:nv] + 1) % nv          # the second entry of a row sits next to its first: stretches of two
+        e = np.ascontiguousarray(np.stack([src, dst], 1))
+        ref = O.run_app("pr", e, nv, iters=8)
+        for opts in (gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB, hub_min_degree=1), gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, hub_min_degree=1, wide_windows=0),
+                     gt.GraphOptions(spmv_variant=gt._lib.GT_SPMV_PB_F32MSG, hub_min_degree=1, wide_windows=1)):
+            G = gt.Graph(options=opts); G.load_edges(e, nv, nv, True, True, True, False, True, gt._2DT_, gt._TCSC_CF_, rank=0, nranks=1)
+            V = gt.Deg_Program(G, True, False, False, gt._COL_); V.execute(1)
+            P = gt.PR_Program(G, True, False, False, gt._ROW_); P.initialize(V); P.execute(8)
+            assert (np.abs(P.V["rank"] - ref["rank"]) / ref["rank"]).max() < PR_RTOL, (per_row, opts.spmv_variant, opts.wide_windows)
+            assert (P.V["degree"] == ref["degree"]).all()
+            P.free(); V.free(); G.free()
+        ref["graph"].close()
+
+
 def test_persistent_phase1_equals_the_dispatched_form(gt, O, monkeypatch):
     """Phase 1 as persistent workgroups drawing chunks from a counter (pb.hip, k_pb_scatter `queue`; round 4) against one workgroup per
     chunk: the same chunks, the same arithmetic inside each -- the value stream is the same bit for bit; the ranks agree to 1e-12
