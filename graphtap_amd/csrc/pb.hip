@@ -1122,9 +1122,11 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #endif
             }
             __syncthreads();
-            bi = mb[0];
+            // (wave-uniform values: through readfirstlane into scalar registers, or every address of the chunk is computed per lane)
+            bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[0]);
             if (bi >= nlaunch) break;
-            c = mb[1]; v0c = mb[2]; v1c = mb[3]; col0 = mb[4];
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[1]); v0c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[2]);
+            v1c = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[3]); col0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb[4]);
         } else {
             const gt_u32x4 d = ldesc[chunk0 + blockIdx.x];
             bi = blockIdx.x; c = d.x; v0c = d.y; v1c = d.z; col0 = d.w;
