@@ -776,21 +776,24 @@ template <int CTRL, int ROW_MASK, class TV> __device__ __forceinline__ TV dpp_ge
 // with 20 / 40 extra dependent SCALAR instructions per group phase 1 lost 2 % / 11 %, with as many vector ones 1 % / 5.5 %
 // (GT_P1_SBURN / GT_P1_VBURN below, profiles/r03/ab_phase2_flush_and_issue_burn.txt): neither port is saturated any more, and
 // keeping the flags complemented to save the s_not of every step changed nothing.)
-template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry_masked(TV t, uint64_t F) {
+// (the four row masks of the in-row steps arrive in scalar register pairs the kernel fills ONCE -- `m`: a 64-bit AND instead of two
+// 32-bit ones with literals in every step)
+struct RowMasks { uint64_t m1, m2, m4, m8; };
+template <class TV, bool IS_MIN> __device__ __forceinline__ TV wave_carry_masked(TV t, uint64_t F, const RowMasks &m) {
     const TV neutral = IS_MIN ? (TV)GT_INF : (TV)0;
     auto comb = [](TV a, TV b) -> TV { if constexpr (IS_MIN) return a < b ? a : b; else return a + b; };
     TV v = t;
 #define GT_MSEG_STEP(CTRL, RM, NEXT_F)                                             \
     {                                                                              \
         const TV vs = dpp_get<CTRL, RM, TV>(v, neutral);                           \
-        v = __builtin_amdgcn_inverse_ballot_w64(~F) ? comb(v, vs) : v;             \
+        v = __builtin_amdgcn_inverse_ballot_w64(F) ? v : comb(v, vs);              \
         F |= (NEXT_F);                                                             \
     }
-    GT_MSEG_STEP(0x111, 0xf, (F << 1) & 0xFFFEFFFEFFFEFFFEull)   // row_shr:1 .. 8: lane l takes lane l - d of its row of 16
-    GT_MSEG_STEP(0x112, 0xf, (F << 2) & 0xFFFCFFFCFFFCFFFCull)
-    GT_MSEG_STEP(0x114, 0xf, (F << 4) & 0xFFF0FFF0FFF0FFF0ull)
-    GT_MSEG_STEP(0x118, 0xf, (F << 8) & 0xFF00FF00FF00FF00ull)
-    GT_MSEG_STEP(0x142, 0xa, (((F >> 15) & 1ull) ? 0x00000000FFFF0000ull : 0ull) | (((F >> 47) & 1ull) ? 0xFFFF000000000000ull : 0ull))   // row_bcast:15 into rows 1, 3
+    GT_MSEG_STEP(0x111, 0xf, (F << 1) & m.m1)   // row_shr:1 .. 8: lane l takes lane l - d of its row of 16 (masks 0xFFFE.., 0xFFFC.., 0xFFF0.., 0xFF00.. per row)
+    GT_MSEG_STEP(0x112, 0xf, (F << 2) & m.m2)
+    GT_MSEG_STEP(0x114, 0xf, (F << 4) & m.m4)
+    GT_MSEG_STEP(0x118, 0xf, (F << 8) & m.m8)
+    GT_MSEG_STEP(0x142, 0xa, ((F >> 47) & 1ull) ? 0xFFFF000000000000ull : 0ull)   // row_bcast:15 into rows 1, 3 (the last step writes rows 2, 3: of the flags only "row 3 is closed by a flag of row 2" is still needed)
     GT_MSEG_STEP(0x143, 0xc, 0ull)                                // row_bcast:31 into rows 2, 3 (the flags are not needed afterwards)
 #undef GT_MSEG_STEP
     return dpp_get<0x138, 0xf, TV>(v, neutral);   // wave_shr:1: the inclusive result of the lane below
@@ -851,6 +854,8 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #endif
     // PERSISTENT form (queue != nullptr; below): compiled in only where it is used -- see the loop at the end of the kernel
     constexpr bool CAN_PERSIST = GT_P1_PERSIST_ALL != 0 || (!IS_MIN && (WIDE || sizeof(TV) == 8));
+    RowMasks rowm{0xFFFEFFFEFFFEFFFEull, 0xFFFCFFFCFFFCFFFCull, 0xFFF0FFF0FFF0FFF0ull, 0xFF00FF00FF00FF00ull};
+    asm volatile("" : "+s"(rowm.m1), "+s"(rowm.m2), "+s"(rowm.m4), "+s"(rowm.m8));   // (opaque to the compiler: they stay in scalar registers, see wave_carry_masked)
     // one chunk: position bi of the launch = chunk c (largest chunks first, see gt_pb_build), its entry range [v0, v1) and first column
     auto chunk = [&](const uint32_t bi, const uint32_t c, const uint32_t v0c, const uint32_t v1c, const uint32_t col0) {
     const uint32_t q0c = v0c >> 2, q1c = v1c >> 2;   // the chunk's quad range (multiples of 64)
@@ -990,7 +995,7 @@ __global__ void __launch_bounds__(P1_THREADS) k_pb_scatter(const uint32_t *__res
 #else
             // (A wave-uniform shortcut for the groups whose 64 lanes ALL hold an end -- the windows of short runs; their carry is one DPP
             // move -- was measured: phase 1 +1.3 %, six rounds: the branch costs every group more than the scan it saves a few.)
-            const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3);
+            const TV carry = wave_carry_masked<TV, IS_MIN>(e3 ? neutral : a3, E0 | E1 | E2 | E3, rowm);
 #endif
 #if defined(GT_P1_SBURN) || defined(GT_P1_VBURN)   // experiment: extra dependent scalar / vector instructions per group (which issue port binds phase 1?)
             {
